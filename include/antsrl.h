@@ -1,0 +1,228 @@
+/*
+ * antsrl.h — C-ABI of libantsrl_hip.so: the MI355X (gfx950) implementation of the
+ * AntsRL environment step loop (RLApi.step + Environment.update), batched over
+ * many independent environments.
+ *
+ * The reference (SelennLamson/AntsRL) is pure Python and has no FFI of its own:
+ * the boundary it exposes is the Python surface of `RLApi` / `Environment`
+ * (SURVEY.md §8(b)).  Each entry point below names the reference interface it
+ * replaces (paths relative to the reference checkout).  The Python shim
+ * `antsrl_amd.RLApi` binds these through ctypes, passing `tensor.data_ptr()`
+ * of torch-ROCm tensors; INTEGRATION.md shows the binding a maintainer of the
+ * reference would add.
+ *
+ * Conventions
+ *  - plain C types only; every buffer is caller-owned DEVICE memory, env-major
+ *    and contiguous; the library never allocates, frees or synchronises inside
+ *    step/update/observe (it only enqueues kernels on the caller's stream);
+ *  - all persistent state lives in ONE caller-provided device workspace whose
+ *    size is reported by antsrl_workspace_bytes();
+ *  - return value 0 = success, negative = error (see ANTSRL_E_*); nothing is
+ *    thrown across the ABI; antsrl_last_error() gives a message for the last
+ *    failure on the calling thread;
+ *  - one handle per device; a handle is not thread-safe.
+ */
+#ifndef ANTSRL_H
+#define ANTSRL_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ANTSRL_ABI_VERSION 1
+
+#define ANTSRL_MAX_CHANNELS 16
+#define ANTSRL_MAX_PSIDE 15                                      /* 2*radius+1 <= 15 */
+#define ANTSRL_MAX_PCELLS (ANTSRL_MAX_PSIDE * ANTSRL_MAX_PSIDE)
+#define ANTSRL_MAX_FILTER_RADIUS 3
+#define ANTSRL_MAX_FILTER_TAPS 49
+#define ANTSRL_MAX_PHERO 4
+
+/* error codes */
+#define ANTSRL_OK 0
+#define ANTSRL_E_INVALID (-1)   /* bad argument / configuration */
+#define ANTSRL_E_NOMEM (-2)     /* workspace too small */
+#define ANTSRL_E_DEVICE (-3)    /* HIP runtime error (launch / no device) */
+#define ANTSRL_E_UNSUPPORTED (-4)
+
+/* perceived-object kinds: one perception channel per entry of
+ * RLApi.perceived_objects (environment/RL_api.py:123-142) */
+enum {
+    ANTSRL_CH_ANTS = 0,    /* RL_api.py:136-142  presence 0/1            */
+    ANTSRL_CH_PHERO = 1,   /* RL_api.py:124-125  phero/max_val (arg = i) */
+    ANTSRL_CH_ANTHILL = 2, /* RL_api.py:130-131  area                    */
+    ANTSRL_CH_WALLS = 3,   /* RL_api.py:128-129  map                     */
+    ANTSRL_CH_FOOD = 4,    /* RL_api.py:126-127  qte                     */
+    ANTSRL_CH_ROCKS = 5    /* RL_api.py:132-135  any(dist < radius)      */
+};
+
+/* reward kinds (environment/rewards/) */
+enum {
+    ANTSRL_REWARD_NONE = 0,        /* Reward base: zeros, reward.py:19,38       */
+    ANTSRL_REWARD_EXPLORATION = 1, /* ExplorationReward, reward_custom.py:8-25  */
+    ANTSRL_REWARD_FOOD = 2,        /* Food_Reward, reward_custom.py:28-40       */
+    ANTSRL_REWARD_ALL = 3          /* All_Rewards, reward_custom.py:43-109      */
+};
+
+/* Static configuration of a batch of environments.  Gathers the constructor
+ * arguments and module constants the reference spreads over RLApi.__init__
+ * (RL_api.py:23), RLApi.setup_perception (RL_api.py:80-93), DELTA (RL_api.py:15),
+ * EnvironmentGenerator.__init__ (generator/environment_generator.py:20-46),
+ * Ants.__init__ (ants.py:18), Pheromone (pheromone.py:5-10,21) and the reward
+ * constructors (rewards/reward_custom.py:44). */
+typedef struct AntsCfg {
+    int32_t abi_version; /* = ANTSRL_ABI_VERSION */
+    int32_t n_envs;      /* E : independent environments in this batch   */
+    int32_t n_ants;      /* N : ants per environment                      */
+    int32_t w, h;        /* grid; cell (x,y) is element [x][y], y fastest */
+    int32_t n_phero;     /* C : pheromone channels (<= ANTSRL_MAX_PHERO)  */
+    int32_t n_rocks;     /* R : circle obstacles per env (0 = none)       */
+    int32_t max_time;    /* Environment.max_time, environment.py:26       */
+
+    /* perception (RLApi.setup_perception) */
+    int32_t perception_radius;                  /* r, side P = 2r+1             */
+    int32_t n_channels;                         /* K = len(perceived_objects)   */
+    int32_t channel_kind[ANTSRL_MAX_CHANNELS];  /* ANTSRL_CH_*                  */
+    int32_t channel_arg[ANTSRL_MAX_CHANNELS];   /* pheromone index for CH_PHERO */
+    int32_t has_mask;                           /* 0: perception_mask is None   */
+    uint8_t mask[ANTSRL_MAX_PCELLS];            /* [P][P] row-major, 1=visible  */
+    uint8_t _pad0[7];
+    double delta;     /* DELTA = 1.1, RL_api.py:15                      */
+    double fwd_delta; /* perception_shift = 4, environment_generator.py:43 */
+
+    /* kinematics (RLApi.__init__, main.py:45-50) */
+    double max_speed, max_rot_speed, carry_speed_reduction, backward_speed_reduction;
+    double max_hold; /* Ants.max_hold = 5, environment_generator.py:93 */
+
+    /* pheromone (pheromone.py:5-10, 36-45) */
+    int32_t has_max_val;      /* Pheromone.max_val is not None                   */
+    int32_t filter_radius;    /* 0..3 ; DIFFUSE_FILTER side = 2*radius+1         */
+    double phero_max_val;     /* 255                                             */
+    double deposit_strength;  /* what activate_pheromone's 256 becomes: 1.0 while
+                                 phero_activation is bool (ants.py:83), 256.0 once
+                                 an agent called activate_all_pheromones(float)   */
+    double phero_threshold;   /* 0.01, pheromone.py:45                           */
+    double filter[ANTSRL_MAX_FILTER_TAPS]; /* DIFFUSE_FILTER [side][side] row-major
+                                 (first index along x), applied as scipy's
+                                 convolve2d(.., 'same', 'fill', 0), pheromone.py:44 */
+
+    /* reward */
+    int32_t reward_kind; /* ANTSRL_REWARD_* */
+    int32_t _pad1;
+    double reward_threshold; /* RLApi.reward_threshold, RL_api.py:32,203 */
+    double fct_explore, fct_food, fct_anthill, fct_explore_holding, fct_headinganthill;
+
+    /* Walls.update jitter (walls.py:28) when no explicit draws are supplied:
+     * counter-based generator keyed on (rng_seed, env, timestep, ant). */
+    uint64_t rng_seed;
+} AntsCfg;
+
+/* Initial state of every environment = what EnvironmentGenerator.generate
+ * (generator/environment_generator.py:52-106) builds.  All device pointers. */
+typedef struct AntsInit {
+    const double *ants_xyt;    /* [E][N][3]  Ants.ants, ants.py:27              */
+    const double *seed;        /* [E][N]     Ants.seed, ants.py:41              */
+    const uint8_t *walls;      /* [E][W][H]  Walls.map, walls.py:14             */
+    const float *food;         /* [E][W][H]  Food.qte, food.py:15               */
+    const int32_t *anthill_xyr;/* [E][3]     Anthill x,y,radius, anthill.py:17  */
+    const double *rocks;       /* [E][R][4]  cx,cy,radius,weight (NULL if R=0),
+                                              circle_obstacles.py:16             */
+    const float *phero;        /* [E][C][W][H] or NULL (= zeros), pheromone.py:28-31 */
+} AntsInit;
+
+typedef struct AntsHandle AntsHandle;
+
+/* selectors for antsrl_read_state: canonical (reference-shaped) layouts */
+enum {
+    ANTSRL_S_ANTS_XYT = 0,     /* double  [E][N][3]                     */
+    ANTSRL_S_PREV_XY = 1,      /* double  [E][N][2]   Ants.prev_ants    */
+    ANTSRL_S_HOLDING = 2,      /* float   [E][N]                        */
+    ANTSRL_S_MANDIBLES = 3,    /* uint8   [E][N]                        */
+    ANTSRL_S_ACTIVATION = 4,   /* float   [E][N][C]   phero_activation  */
+    ANTSRL_S_PHERO = 5,        /* float   [E][C][W][H]                  */
+    ANTSRL_S_FOOD = 6,         /* float   [E][W][H]                     */
+    ANTSRL_S_EXPLORED = 7,     /* uint8   [E][W][H]   reward explored_map */
+    ANTSRL_S_ANTHILL_FOOD = 8, /* double  [E]         Anthill.food      */
+    ANTSRL_S_ROCK_CENTERS = 9, /* double  [E][R][2]                     */
+    ANTSRL_S_TIMESTEP = 10,    /* int32   [E]                           */
+    ANTSRL_S_REWARD_STATE = 11,/* uint8   [E][N]      Ants.reward_state */
+    ANTSRL_S_WALLS = 12,       /* uint8   [E][W][H]                     */
+    ANTSRL_S_ANTHILL_AREA = 13,/* uint8   [E][W][H]   Anthill.area      */
+    ANTSRL_S_SEED = 14,        /* float   [E][N]                        */
+    ANTSRL_S_COUNT_
+};
+
+/* Library / ABI version (ANTSRL_ABI_VERSION of the build). */
+int antsrl_abi_version(void);
+
+/* Message for the last error returned on this thread ("" if none). */
+const char *antsrl_last_error(void);
+
+/* Bytes of device workspace a batch with this configuration needs.
+ * No reference counterpart (the reference allocates numpy arrays per object). */
+int antsrl_workspace_bytes(const AntsCfg *cfg, size_t *bytes);
+
+/* Creates a handle over a caller-owned device workspace (>= workspace_bytes,
+ * 256-byte aligned).  Replaces RLApi.__init__ (environment/RL_api.py:23) +
+ * RLApi.setup_perception (RL_api.py:80-93).  Host-only: touches no device state. */
+int antsrl_create(const AntsCfg *cfg, void *workspace, size_t workspace_bytes, AntsHandle **out);
+
+void antsrl_destroy(AntsHandle *h);
+
+/* Loads the initial state of all E environments ("reset"): replaces
+ * EnvironmentGenerator.generate (generator/environment_generator.py:52-106)
+ * object construction, Anthill.__init__ area rasterisation (anthill.py:28-33),
+ * RLApi.register_ants (RL_api.py:57-66) and Reward.setup (rewards/reward.py:12-19,
+ * reward_custom.py:13-15,33-35,65-77).  timestep := 1 (environment.py:27). */
+int antsrl_reset(AntsHandle *h, const AntsInit *init, void *stream);
+
+/* RLApi.step (environment/RL_api.py:168-204): mandibles/food exchange, pheromone
+ * activation, rotate, forward move, observation, reward, done.
+ *   rotation  int8 [E][N] in {-1,0,1} or NULL (= leave theta unchanged, RL_api.py:190)
+ *   phero     int8 [E][N] in {0,1,2}  or NULL (= leave activation, RL_api.py:187)
+ *   obs         float [E][N][P][P][K]   perception  (may be NULL: skip the write)
+ *   agent_state float [E][N][2]         [holding, seed], RL_api.py:160-162
+ *   reward      float [E][N]            Reward.step, rewards/reward.py:38
+ *   done        uint8 [E]               RL_api.py:200                         */
+int antsrl_step(AntsHandle *h, const int8_t *rotation, const int8_t *phero, float *obs,
+                float *agent_state, float *reward, uint8_t *done, void *stream);
+
+/* RLApi.observation (environment/RL_api.py:96-165) on the current state, including
+ * its reward side effects (reward.observation, RL_api.py:164).  reward may be NULL. */
+int antsrl_observe(AntsHandle *h, float *obs, float *agent_state, float *reward, void *stream);
+
+/* Environment.update (environment/environment.py:42-47): timestep += 1, then
+ * Walls (walls.py:22-30), CircleObstacles (circle_obstacles.py:32-58), Pheromone
+ * (pheromone.py:43-45), Ants (ants.py:123-130), Anthill (anthill.py:41-46).
+ *   wall_jitter  double [E][N] or NULL.  When given, entry k of env e is the k-th
+ *   value np.random.random(k) would have returned in Walls.update (walls.py:28):
+ *   the k-th colliding ant, in ant-index order, consumes it.  NULL = built-in
+ *   counter-based generator (AntsCfg.rng_seed). */
+int antsrl_update(AntsHandle *h, const double *wall_jitter, void *stream);
+
+/* main.py:98 followed by main.py:131 — one full simulation step. */
+int antsrl_step_update(AntsHandle *h, const int8_t *rotation, const int8_t *phero,
+                       const double *wall_jitter, float *obs, float *agent_state, float *reward,
+                       uint8_t *done, void *stream);
+
+/* Ants.activate_all_pheromones (environment/ants.py:86-87).  act: float [E][N][C].
+ * new_deposit_strength > 0 also changes AntsCfg.deposit_strength (the dtype switch
+ * of SURVEY.md §8(a) A4); pass 0 to keep it. */
+int antsrl_set_activation(AntsHandle *h, const float *act, double new_deposit_strength,
+                          void *stream);
+
+/* Copies one piece of state into a caller device buffer in the canonical
+ * reference-shaped layout (ANTSRL_S_*).  Replaces attribute reads such as
+ * api.ants.ants, pheromone.phero, food.qte, anthill.food. */
+int antsrl_read_state(AntsHandle *h, int which, void *dst, void *stream);
+
+/* Size in bytes of what antsrl_read_state(which) writes. */
+int antsrl_state_bytes(const AntsHandle *h, int which, size_t *bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ANTSRL_H */

@@ -1,0 +1,553 @@
+/*
+ * antsrl_oracle.c — CPU restatement of the AntsRL environment step loop.
+ *
+ * TEST INFRASTRUCTURE ONLY (see antsrl_oracle.h).  Plain C, float64 throughout like
+ * the reference, explicit per-ant / per-cell loops, one environment at a time
+ * (environments are independent; the batch wrappers at the bottom optionally spread
+ * them over OpenMP threads for the timed cpu_baseline leg of bench.py).
+ *
+ * Parity status: PINNED.  tests/test_oracle_golden.py checks this file against
+ * golden vectors recorded from the real reference (tests/golden/make_golden.py):
+ * ant x/y/theta, holding, mandibles, food, anthill.food, rock centres, explored map,
+ * perception, agent_state, reward, done — bit-exact in float64; pheromone bit-exact
+ * for the shipped centre-only filter and within 1e-12 relative when a diffusion
+ * filter is patched in (scipy's summation order is not restated).
+ *
+ * Build with -ffp-contract=off: numpy rounds every product before adding, so fused
+ * multiply-add must not be formed.
+ *
+ * All file:line citations are relative to the reference checkout.
+ */
+#include "antsrl_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define PI_D 3.141592653589793 /* np.pi */
+
+/* np.mod on float64 (numpy npy_divmod semantics): result takes the sign of b. */
+static double np_mod(double a, double b)
+{
+    double r = fmod(a, b);
+    if (r != 0.0) {
+        if ((b < 0) != (r < 0)) r += b;
+    } else {
+        r = copysign(0.0, b);
+    }
+    return r;
+}
+
+/* Ants.warp_xy, environment/ants.py:69-71.  np.mod(-1e-17, W) rounds to exactly W,
+ * where the reference would raise IndexError on its next grid access (SURVEY §8(a)
+ * A2); this restatement maps that single value to 0 instead. */
+static double warp_coord(double v, double size)
+{
+    double r = np_mod(v, size);
+    if (r >= size) r = 0.0;
+    return r;
+}
+
+/* python int % int for the wrapped perception coordinates, RL_api.py:118-119 */
+static long imod(long a, long b)
+{
+    long r = a % b;
+    if (r < 0) r += b;
+    return r;
+}
+
+/* ---- counter-based jitter generator (specification shared with the device) ---- */
+static uint64_t mix64(uint64_t z)
+{
+    z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ULL;
+    z ^= z >> 27; z *= 0x94D049BB133111EBULL;
+    z ^= z >> 31;
+    return z;
+}
+
+double oracle_jitter_u01(uint64_t seed, uint32_t env, uint32_t timestep, uint32_t ant)
+{
+    uint64_t k = mix64(seed + 0x9E3779B97F4A7C15ULL * ((uint64_t)env + 1));
+    k = mix64(k ^ (0xD1B54A32D192ED03ULL * ((uint64_t)timestep + 1)));
+    k = mix64(k + 0x9E3779B97F4A7C15ULL * ((uint64_t)ant + 1));
+    return (double)(k >> 11) * (1.0 / 9007199254740992.0); /* 53-bit mantissa, [0,1) */
+}
+
+int oracle_max_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+/* per-env views ------------------------------------------------------------- */
+typedef struct EnvView {
+    int N, W, H, C, R;
+    double *x, *y, *theta, *prev_x, *prev_y, *holding, *seed, *activation;
+    uint8_t *mandibles, *reward_state;
+    double *phero, *food;
+    uint8_t *walls, *area, *explored;
+    int32_t *xyr;
+    double *anthill_food;
+    double *rcx, *rcy, *rrad, *rwt;
+    int32_t *timestep;
+    double *prev_holding, *prev_dist;
+    uint8_t *primed;
+} EnvView;
+
+static EnvView view(const AntsCfg *c, OracleState *s, int e)
+{
+    EnvView v;
+    size_t N = c->n_ants, G = (size_t)c->w * c->h, C = c->n_phero, R = c->n_rocks;
+    v.N = c->n_ants; v.W = c->w; v.H = c->h; v.C = c->n_phero; v.R = c->n_rocks;
+    v.x = s->x + e * N; v.y = s->y + e * N; v.theta = s->theta + e * N;
+    v.prev_x = s->prev_x + e * N; v.prev_y = s->prev_y + e * N;
+    v.holding = s->holding + e * N; v.seed = s->seed + e * N;
+    v.activation = s->activation + e * N * C;
+    v.mandibles = s->mandibles + e * N; v.reward_state = s->reward_state + e * N;
+    v.phero = s->phero + e * C * G; v.food = s->food + e * G;
+    v.walls = s->walls + e * G; v.area = s->anthill_area + e * G; v.explored = s->explored + e * G;
+    v.xyr = s->anthill_xyr + 3 * e; v.anthill_food = s->anthill_food + e;
+    v.rcx = s->rock_cx ? s->rock_cx + e * R : NULL; v.rcy = s->rock_cy ? s->rock_cy + e * R : NULL;
+    v.rrad = s->rock_radius ? s->rock_radius + e * R : NULL;
+    v.rwt = s->rock_weight ? s->rock_weight + e * R : NULL;
+    v.timestep = s->timestep + e;
+    v.prev_holding = s->prev_holding + e * N; v.prev_dist = s->prev_dist + e * N;
+    v.primed = s->reward_primed + e;
+    return v;
+}
+
+/* All_Rewards.compute_distance, rewards/reward_custom.py:59-60 */
+static double anthill_dist(const EnvView *v, double x, double y)
+{
+    double dx = x - (double)v->xyr[0], dy = y - (double)v->xyr[1];
+    return sqrt(dx * dx + dy * dy);
+}
+
+/* ---------------------------------------------------------------------------
+ * reset: Anthill.__init__ (environment/anthill.py:17-33), Ants.__init__
+ * (ants.py:18-41), RLApi.register_ants (RL_api.py:57-66), Reward.setup
+ * (rewards/reward.py:12-19; reward_custom.py:13-15, 33-35, 65-77),
+ * Environment.__init__ timestep = 1 (environment.py:27).
+ * ------------------------------------------------------------------------- */
+static void env_reset(const AntsCfg *c, EnvView *v)
+{
+    int N = v->N, W = v->W, H = v->H;
+    /* anthill.py:28-33: area[x,y] = sqrt((ax-x)^2+(ay-y)^2) <= radius, integer ax,ay,r */
+    long ax = v->xyr[0], ay = v->xyr[1], ar = v->xyr[2];
+    for (long x = 0; x < W; ++x)
+        for (long y = 0; y < H; ++y) {
+            double d = sqrt((double)((ax - x) * (ax - x) + (ay - y) * (ay - y)));
+            v->area[x * H + y] = d <= (double)ar;
+        }
+    *v->anthill_food = 0.0;
+    for (int i = 0; i < N; ++i) {
+        /* ants.py:27-30: copy, warp_xy, prev_ants = copy.  theta is NOT wrapped. */
+        v->x[i] = warp_coord(v->x[i], (double)W);
+        v->y[i] = warp_coord(v->y[i], (double)H);
+        v->prev_x[i] = v->x[i]; v->prev_y[i] = v->y[i];
+        v->mandibles[i] = 0; v->holding[i] = 0.0; v->reward_state[i] = 0;
+        for (int k = 0; k < v->C; ++k) v->activation[i * v->C + k] = 0.0; /* ants.py:32,83 */
+        v->prev_holding[i] = 0.0;
+        v->prev_dist[i] = anthill_dist(v, v->x[i], v->y[i]); /* reward_custom.py:77 */
+    }
+    memset(v->explored, 0, (size_t)W * H); /* reward_custom.py:15,68 */
+    *v->timestep = 1;
+    *v->primed = 0;
+    (void)c;
+}
+
+/* ---------------------------------------------------------------------------
+ * RLApi.observation, environment/RL_api.py:96-165  (+ setup_perception :80-93,
+ * reward.observation hooks rewards/reward_custom.py:17-22, 37-40, 79-106)
+ * ------------------------------------------------------------------------- */
+static void env_observe(const AntsCfg *c, EnvView *v, double *obs, double *agent_state,
+                        double *reward, long *scratch_cells, uint8_t *ants_map)
+{
+    const int N = v->N, W = v->W, H = v->H, K = c->n_channels;
+    const int r = c->perception_radius, P = 2 * r + 1, PP = P * P;
+
+    /* RL_api.py:136-142: presence map from floor(xy); `+= 1` with repeated indices
+     * does not accumulate, so the map is 0/1. */
+    int need_ants = 0;
+    for (int k = 0; k < K; ++k) need_ants |= c->channel_kind[k] == ANTSRL_CH_ANTS;
+    if (need_ants) {
+        memset(ants_map, 0, (size_t)W * H);
+        for (int i = 0; i < N; ++i) {
+            long ix = imod((long)v->x[i], W), iy = imod((long)v->y[i], H);
+            ants_map[ix * H + iy] = 1;
+        }
+    }
+
+    for (int i = 0; i < N; ++i) {
+        /* RL_api.py:100-104 */
+        double xf = v->x[i], yf = v->y[i];
+        double tf = v->theta[i] + PI_D * 0.5;
+        if (c->fwd_delta != 0.0) {
+            xf += cos(v->theta[i]) * c->fwd_delta;
+            yf += sin(v->theta[i]) * c->fwd_delta;
+        }
+        double ct = cos(tf), st = sin(tf); /* :107-108 */
+        for (int a = 0; a < P; ++a)
+            for (int b = 0; b < P; ++b) {
+                /* :92-93  coords[a][b] = (arange[b], arange[a]) * DELTA */
+                double px = (double)(b - r) * c->delta, py = (double)(a - r) * c->delta;
+                /* :110-111 rotation, :114 translation */
+                double rx = ct * px - st * py;
+                double ry = st * px + ct * py;
+                double fx = rx + xf, fy = ry + yf;
+                /* :117-119 np.round (half to even) -> int -> mod */
+                long ix = imod((long)rint(fx), W), iy = imod((long)rint(fy), H);
+                long cell = ix * H + iy;
+                scratch_cells[(size_t)i * PP + a * P + b] = cell;
+                if (!obs) continue;
+                double m = c->has_mask ? (double)c->mask[a * P + b] : 1.0;
+                double *o = obs + (((size_t)i * P + a) * P + b) * K;
+                for (int k = 0; k < K; ++k) {
+                    double p = 0.0;
+                    switch (c->channel_kind[k]) {
+                    case ANTSRL_CH_PHERO: /* :124-125 */
+                        p = v->phero[(size_t)c->channel_arg[k] * W * H + cell] / c->phero_max_val;
+                        break;
+                    case ANTSRL_CH_FOOD: p = v->food[cell]; break;             /* :126-127 */
+                    case ANTSRL_CH_WALLS: p = (double)v->walls[cell]; break;    /* :128-129 */
+                    case ANTSRL_CH_ANTHILL: p = (double)v->area[cell]; break;   /* :130-131 */
+                    case ANTSRL_CH_ROCKS: {                                     /* :132-135 */
+                        int any = 0;
+                        for (int q = 0; q < v->R; ++q) {
+                            double vx = (double)ix - v->rcx[q], vy = (double)iy - v->rcy[q];
+                            double d = sqrt(vx * vx + vy * vy);
+                            any |= d < v->rrad[q];
+                        }
+                        p = (double)any;
+                    } break;
+                    case ANTSRL_CH_ANTS: p = (double)ants_map[cell]; break;     /* :142 */
+                    default: break;
+                    }
+                    /* :147-148 perception = mask * (perception + 1) - 1 */
+                    o[k] = c->has_mask ? m * (p + 1.0) - 1.0 : p;
+                }
+            }
+        /* :160-162 */
+        agent_state[2 * i + 0] = v->holding[i];
+        agent_state[2 * i + 1] = v->seed[i];
+    }
+
+    /* ---- reward.observation(abs_coords, perception, agent_state), RL_api.py:164 ---- */
+    const int kind = c->reward_kind;
+    if (kind == ANTSRL_REWARD_NONE) { /* rewards/reward.py:19,27: zeros, no-op */
+        for (int i = 0; i < N; ++i) reward[i] = 0.0;
+        return;
+    }
+    /* Alias quirk: Food_Reward/All_Rewards.setup bind ants_holding to the LIVE
+     * Ants.holding array (reward_custom.py:35,68), which Ants.update_mandibles mutates
+     * in place (ants.py:117), so the first observation after setup always sees
+     * delta-holding == 0; afterwards ants_holding is the previous agent_state column. */
+    if (!*v->primed) {
+        for (int i = 0; i < N; ++i) v->prev_holding[i] = v->holding[i];
+        *v->primed = 1;
+    }
+    if (kind == ANTSRL_REWARD_EXPLORATION) {
+        /* reward_custom.py:17-22: count unexplored among ALL P*P cells (mask ignored)
+         * against the pre-observation map, /10, then mark. */
+        for (int i = 0; i < N; ++i) {
+            long cnt = 0;
+            for (int q = 0; q < PP; ++q) cnt += 1 - v->explored[scratch_cells[(size_t)i * PP + q]];
+            reward[i] = (double)cnt / 10.0;
+        }
+        for (size_t q = 0; q < (size_t)N * PP; ++q) v->explored[scratch_cells[q]] = 1;
+    } else if (kind == ANTSRL_REWARD_FOOD) {
+        /* reward_custom.py:37-40 */
+        for (int i = 0; i < N; ++i) {
+            double d = v->holding[i] - v->prev_holding[i];
+            if (d < 0) d = 10.0;
+            reward[i] = d;
+            v->prev_holding[i] = v->holding[i];
+        }
+    } else { /* ANTSRL_REWARD_ALL, reward_custom.py:79-106 */
+        int explore = c->fct_explore != 0.0 || c->fct_explore_holding != 0.0;
+        for (int i = 0; i < N; ++i) {
+            double rw = 0.0;                                   /* :80 */
+            double dh = v->holding[i] - v->prev_holding[i];    /* :82 */
+            double r_food = dh < 0 ? 0.0 : dh;                 /* :84 */
+            double r_anthill = dh < 0 ? 1.0 : 0.0;             /* :97-98 (dh>0 -> 0, dh==0 stays 0) */
+            v->prev_holding[i] = v->holding[i];                /* :85 */
+            if (explore) {                                     /* :87-94 */
+                long cnt = 0;
+                for (int q = 0; q < PP; ++q) cnt += 1 - v->explored[scratch_cells[(size_t)i * PP + q]];
+                double re = (double)cnt / 10.0;
+                re = (v->holding[i] == 0.0) ? re * c->fct_explore : re * c->fct_explore_holding;
+                rw += re;
+            }
+            double nd = anthill_dist(v, v->x[i], v->y[i]);     /* :102 */
+            double heading = (double)((v->prev_dist[i] > nd) * (v->holding[i] > 0)) * 0.1; /* :103 */
+            v->prev_dist[i] = nd;                              /* :104 */
+            rw += r_food * c->fct_food + r_anthill * c->fct_anthill + heading * c->fct_headinganthill; /* :106 */
+            reward[i] = rw;
+        }
+        if (explore)
+            for (size_t q = 0; q < (size_t)N * PP; ++q) v->explored[scratch_cells[q]] = 1; /* :93 */
+    }
+}
+
+/* ---------------------------------------------------------------------------
+ * RLApi.step, environment/RL_api.py:168-204
+ * ------------------------------------------------------------------------- */
+static void env_step(const AntsCfg *c, EnvView *v, const int8_t *rot, const int8_t *ph, double *obs,
+                     double *agent_state, double *reward, uint8_t *done, long *scratch_cells,
+                     uint8_t *ants_map, double *tmp /* 3N */, uint8_t *newm /* N */)
+{
+    const int N = v->N, W = v->W, H = v->H, K = c->n_channels;
+    (void)W;
+    /* :178-185 mandible target, iterating perceived_objects in order */
+    for (int i = 0; i < N; ++i) {
+        long cprev = (long)v->prev_x[i] * H + (long)v->prev_y[i];
+        int m = v->mandibles[i];
+        for (int k = 0; k < K; ++k) {
+            if (c->channel_kind[k] == ANTSRL_CH_FOOD)
+                m = (v->food[cprev] > 0) | m;                                    /* :182 */
+            else if (c->channel_kind[k] == ANTSRL_CH_ANTHILL)
+                m = (1 - v->area[(long)v->x[i] * H + (long)v->y[i]]) & m;        /* :184 */
+        }
+        newm[i] = (uint8_t)m;
+    }
+    /* Ants.update_mandibles, environment/ants.py:102-117 */
+    double *q_old = tmp, *taken = tmp + N, *dropped = tmp + 2 * N;
+    for (int i = 0; i < N; ++i) {
+        int closing = newm[i] & (1 - v->mandibles[i]);  /* :103 */
+        int opening = (1 - newm[i]) & v->mandibles[i];  /* :104 */
+        long cprev = (long)v->prev_x[i] * H + (long)v->prev_y[i];
+        q_old[i] = v->food[cprev];
+        taken[i] = fmin(c->max_hold, fmax(0.0, q_old[i])) * (double)closing; /* :111 */
+        dropped[i] = v->holding[i] * (double)opening;                         /* :114 */
+    }
+    for (int i = 0; i < N; ++i) {
+        long cprev = (long)v->prev_x[i] * H + (long)v->prev_y[i];
+        /* :116 fancy-index `+=`: every ant adds to the PRE-update value and the last
+         * ant (in index order) on a cell wins. */
+        v->food[cprev] = q_old[i] + (dropped[i] - taken[i]);
+        v->holding[i] += taken[i] - dropped[i];               /* :117 */
+        v->mandibles[i] = newm[i];                            /* :107 */
+    }
+    /* :187-188 Ants.activate_pheromone, ants.py:89-96 (hard-codes two channels) */
+    if (ph) {
+        for (int i = 0; i < N; ++i) {
+            double a0 = 0.0, a1 = 0.0;
+            if (ph[i] == 1) a0 = c->deposit_strength;
+            else if (ph[i] != 0) a1 = c->deposit_strength;
+            v->activation[i * v->C + 0] = a0;
+            if (v->C > 1) v->activation[i * v->C + 1] = a1;
+        }
+    }
+    /* :190-191 Ants.rotate_ants, ants.py:65-67 (+ warp_theta :62-63) */
+    if (rot)
+        for (int i = 0; i < N; ++i)
+            v->theta[i] = np_mod(v->theta[i] + (double)rot[i] * c->max_rot_speed, 2 * PI_D);
+    /* :194-196 forward move, Ants.forward_ants ants.py:77-80, translate/warp :69-75 */
+    for (int i = 0; i < N; ++i) {
+        double fwd = 1.0 * c->max_speed * (1 - v->holding[i] * c->carry_speed_reduction);
+        if (fwd < 0) fwd *= c->backward_speed_reduction;
+        double ax = cos(v->theta[i]) * fwd, ay = sin(v->theta[i]) * fwd;
+        v->x[i] = warp_coord(v->x[i] + ax, (double)v->W);
+        v->y[i] = warp_coord(v->y[i] + ay, (double)v->H);
+    }
+    /* :198 */
+    env_observe(c, v, obs, agent_state, reward, scratch_cells, ants_map);
+    /* :200 */
+    *done = (uint8_t)(c->max_time == *v->timestep);
+    /* :203 Ants.give_reward, ants.py:119-121 */
+    for (int i = 0; i < N; ++i)
+        if (reward[i] - c->reward_threshold > 0) v->reward_state[i] = 255;
+}
+
+/* ---------------------------------------------------------------------------
+ * Environment.update, environment/environment.py:42-47
+ * ------------------------------------------------------------------------- */
+static int env_update(const AntsCfg *c, EnvView *v, int env_index, const double *jitter,
+                      double *grid_tmp /* W*H */)
+{
+    const int N = v->N, W = v->W, H = v->H, C = v->C, R = v->R;
+    const size_t G = (size_t)W * H;
+    *v->timestep += 1; /* :45 */
+
+    /* --- Walls.update (step -1), environment/walls.py:22-30 --- */
+    int hits = 0;
+    for (int i = 0; i < N; ++i) {
+        long cell = (long)v->x[i] * H + (long)v->y[i];   /* :25 */
+        if (v->walls[cell]) {                             /* :26 */
+            v->x[i] = v->prev_x[i]; v->y[i] = v->prev_y[i]; /* :27 */
+            double u = jitter ? jitter[hits]
+                              : oracle_jitter_u01(c->rng_seed, (uint32_t)env_index,
+                                                  (uint32_t)*v->timestep, (uint32_t)i);
+            v->theta[i] += u - 0.5;                       /* :28 (theta not re-wrapped) */
+            ++hits;
+        }
+    }
+    for (int k = 0; k < C; ++k)                           /* :30 */
+        for (size_t g = 0; g < G; ++g)
+            if (v->walls[g]) v->phero[k * G + g] = 0.0;
+
+    /* --- CircleObstacles.update (step 0), environment/circle_obstacles.py:32-58 --- */
+    if (R > 0) {
+        for (int q = 0; q < R; ++q) { /* pass 1 :35-40, sum over ants in index order */
+            double sx = 0.0, sy = 0.0;
+            for (int i = 0; i < N; ++i) {
+                double vx = v->rcx[q] - v->x[i], vy = v->rcy[q] - v->y[i];
+                double d = sqrt(vx * vx + vy * vy);
+                double f = 1 - v->rrad[q] / (d + 0.001);
+                double px = vx * f, py = vy * f;
+                if (d > v->rrad[q]) { px = 0.0; py = 0.0; }
+                sx += px; sy += py;
+            }
+            v->rcx[q] -= sx / v->rwt[q];
+            v->rcy[q] -= sy / v->rwt[q];
+        }
+        for (int i = 0; i < N; ++i) { /* pass 2 :53-58 with the UPDATED centres */
+            double sx = 0.0, sy = 0.0;
+            for (int q = 0; q < R; ++q) {
+                double vx = v->rcx[q] - v->x[i], vy = v->rcy[q] - v->y[i];
+                double d = sqrt(vx * vx + vy * vy);
+                double f = 1 - v->rrad[q] / (d + 0.001);
+                double px = vx * f, py = vy * f;
+                if (d > v->rrad[q]) { px = 0.0; py = 0.0; }
+                sx += px; sy += py;
+            }
+            v->x[i] = warp_coord(v->x[i] + sx, (double)W); /* translate_ants, ants.py:73-75 */
+            v->y[i] = warp_coord(v->y[i] + sy, (double)H);
+        }
+    }
+
+    /* --- Pheromone.update (step 0), environment/pheromone.py:43-45 --- */
+    {
+        const int fr = c->filter_radius, fs = 2 * fr + 1;
+        for (int k = 0; k < C; ++k) {
+            double *p = v->phero + k * G;
+            if (fr == 0) {
+                for (size_t g = 0; g < G; ++g) {
+                    double o = p[g] * c->filter[0];
+                    p[g] = o < c->phero_threshold ? 0.0 : o;
+                }
+            } else {
+                /* convolve2d(phero, F, 'same', 'fill', 0):
+                 * out[x,y] = sum_{a,b} F[a,b] * in[x - a + fr, y - b + fr], zero outside */
+                for (int x = 0; x < W; ++x)
+                    for (int y = 0; y < H; ++y) {
+                        double acc = 0.0;
+                        for (int a = 0; a < fs; ++a) {
+                            int sx = x - a + fr;
+                            if (sx < 0 || sx >= W) continue;
+                            for (int b = 0; b < fs; ++b) {
+                                int sy = y - b + fr;
+                                if (sy < 0 || sy >= H) continue;
+                                acc += c->filter[a * fs + b] * p[(size_t)sx * H + sy];
+                            }
+                        }
+                        grid_tmp[(size_t)x * H + y] = acc < c->phero_threshold ? 0.0 : acc;
+                    }
+                memcpy(p, grid_tmp, G * sizeof(double));
+            }
+        }
+    }
+
+    /* --- Ants.update (step 999), environment/ants.py:123-130 --- */
+    for (int i = 0; i < N; ++i) { v->prev_x[i] = v->x[i]; v->prev_y[i] = v->y[i]; } /* :124 */
+    for (int k = 0; k < C; ++k) {
+        /* Pheromone.add_pheromones, pheromone.py:36-41: last writer wins, then
+         * whole-grid minimum with max_val. */
+        double *p = v->phero + k * G;
+        for (int i = 0; i < N; ++i) grid_tmp[i] = p[(long)v->x[i] * H + (long)v->y[i]];
+        for (int i = 0; i < N; ++i)
+            p[(long)v->x[i] * H + (long)v->y[i]] = grid_tmp[i] + v->activation[i * C + k];
+        if (c->has_max_val && N > 0)
+            for (size_t g = 0; g < G; ++g) p[g] = fmin(p[g], c->phero_max_val);
+    }
+    for (int i = 0; i < N; ++i) /* :130 */
+        v->reward_state[i] = (uint8_t)((double)v->reward_state[i] * 0.9);
+
+    /* --- Anthill.update (step 1000), environment/anthill.py:41-46 --- */
+    {
+        double gain_sum = 0.0;
+        for (size_t g = 0; g < G; ++g) {
+            double gain = v->food[g] * (double)v->area[g];
+            v->food[g] -= gain;
+            gain_sum += gain;
+        }
+        *v->anthill_food += gain_sum;
+    }
+    return hits;
+}
+
+/* ---- batch wrappers -------------------------------------------------------- */
+void oracle_reset(const AntsCfg *c, OracleState *s)
+{
+    for (int e = 0; e < c->n_envs; ++e) {
+        EnvView v = view(c, s, e);
+        env_reset(c, &v);
+    }
+}
+
+void oracle_observe(const AntsCfg *c, OracleState *s, double *obs, double *agent_state,
+                    double *reward, int n_threads)
+{
+    const size_t N = c->n_ants, P = 2 * c->perception_radius + 1, K = c->n_channels;
+    const size_t G = (size_t)c->w * c->h;
+    (void)n_threads;
+#pragma omp parallel num_threads(n_threads > 0 ? n_threads : 1)
+    {
+        long *cells = (long *)malloc(sizeof(long) * N * P * P);
+        uint8_t *amap = (uint8_t *)malloc(G);
+#pragma omp for schedule(dynamic, 1)
+        for (int e = 0; e < c->n_envs; ++e) {
+            EnvView v = view(c, s, e);
+            env_observe(c, &v, obs ? obs + e * N * P * P * K : NULL, agent_state + e * N * 2,
+                        reward + e * N, cells, amap);
+        }
+        free(cells); free(amap);
+    }
+}
+
+void oracle_step(const AntsCfg *c, OracleState *s, const int8_t *rotation, const int8_t *phero,
+                 double *obs, double *agent_state, double *reward, uint8_t *done, int n_threads)
+{
+    const size_t N = c->n_ants, P = 2 * c->perception_radius + 1, K = c->n_channels;
+    const size_t G = (size_t)c->w * c->h;
+    (void)n_threads;
+#pragma omp parallel num_threads(n_threads > 0 ? n_threads : 1)
+    {
+        long *cells = (long *)malloc(sizeof(long) * N * P * P);
+        uint8_t *amap = (uint8_t *)malloc(G);
+        double *tmp = (double *)malloc(sizeof(double) * 3 * N);
+        uint8_t *newm = (uint8_t *)malloc(N);
+#pragma omp for schedule(dynamic, 1)
+        for (int e = 0; e < c->n_envs; ++e) {
+            EnvView v = view(c, s, e);
+            env_step(c, &v, rotation ? rotation + e * N : NULL, phero ? phero + e * N : NULL,
+                     obs ? obs + e * N * P * P * K : NULL, agent_state + e * N * 2, reward + e * N,
+                     done + e, cells, amap, tmp, newm);
+        }
+        free(cells); free(amap); free(tmp); free(newm);
+    }
+}
+
+void oracle_update(const AntsCfg *c, OracleState *s, const double *wall_jitter, int32_t *hit_count,
+                   int n_threads)
+{
+    const size_t N = c->n_ants, G = (size_t)c->w * c->h;
+    (void)n_threads;
+#pragma omp parallel num_threads(n_threads > 0 ? n_threads : 1)
+    {
+        double *gt = (double *)malloc(sizeof(double) * (G > N ? G : N));
+#pragma omp for schedule(dynamic, 1)
+        for (int e = 0; e < c->n_envs; ++e) {
+            EnvView v = view(c, s, e);
+            int hits = env_update(c, &v, e, wall_jitter ? wall_jitter + e * N : NULL, gt);
+            if (hit_count) hit_count[e] = hits;
+        }
+        free(gt);
+    }
+}
