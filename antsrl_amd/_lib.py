@@ -1,0 +1,80 @@
+"""ctypes binding of libantsrl_hip.so (include/antsrl.h).  Fails loudly: there is no CPU
+fallback in the product path."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+from .config import AntsCfg, AntsInit
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libantsrl_hip.so")
+
+#: every symbol include/antsrl.h declares
+EXPORTS = ("antsrl_abi_version", "antsrl_cfg_size", "antsrl_last_error", "antsrl_workspace_bytes", "antsrl_create",
+           "antsrl_destroy", "antsrl_reset", "antsrl_step", "antsrl_observe", "antsrl_update",
+           "antsrl_step_update", "antsrl_set_timing_events", "antsrl_set_activation", "antsrl_read_state", "antsrl_state_bytes")
+
+_lib = None
+
+
+class AntsrlError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise AntsrlError(
+            "libantsrl_hip.so is missing (%s): build it with `python -m antsrl_amd.build` "
+            "(hipcc, gfx950).  There is no CPU fallback." % LIB_PATH)
+    # PyTorch-ROCm ships its own libamdhip64 / libhsa-runtime64 (same sonames as /opt/rocm).
+    # A process must hold ONE HIP runtime: import torch first so the NEEDED entries of
+    # libantsrl_hip.so bind to the runtime torch's streams and tensors live in.  (Loaded the
+    # other way round, launches fail with "no ROCm-capable device is detected".)
+    import torch  # noqa: F401
+    lib = C.CDLL(LIB_PATH)
+    vp, i32 = C.c_void_p, C.c_int
+    lib.antsrl_abi_version.restype = i32
+    lib.antsrl_last_error.restype = C.c_char_p
+    lib.antsrl_workspace_bytes.argtypes = [C.POINTER(AntsCfg), C.POINTER(C.c_size_t)]
+    lib.antsrl_create.argtypes = [C.POINTER(AntsCfg), vp, C.c_size_t, C.POINTER(vp)]
+    lib.antsrl_destroy.argtypes = [vp]
+    lib.antsrl_destroy.restype = None
+    lib.antsrl_reset.argtypes = [vp, C.POINTER(AntsInit), vp]
+    lib.antsrl_step.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.antsrl_observe.argtypes = [vp, vp, vp, vp, vp]
+    lib.antsrl_update.argtypes = [vp, vp, vp]
+    lib.antsrl_step_update.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.antsrl_set_timing_events.argtypes = [vp, C.POINTER(vp)]
+    lib.antsrl_set_activation.argtypes = [vp, vp, C.c_double, vp]
+    lib.antsrl_read_state.argtypes = [vp, i32, vp, vp]
+    lib.antsrl_state_bytes.argtypes = [vp, i32, C.POINTER(C.c_size_t)]
+    for name in EXPORTS:
+        getattr(lib, name)  # AttributeError if the build lost a symbol
+    lib.antsrl_cfg_size.restype = C.c_size_t
+    from .config import ABI_VERSION
+    if lib.antsrl_abi_version() != ABI_VERSION:
+        raise AntsrlError("ABI version mismatch: library %d, binding %d" % (lib.antsrl_abi_version(), ABI_VERSION))
+    if lib.antsrl_cfg_size() != C.sizeof(AntsCfg):
+        raise AntsrlError("AntsCfg layout mismatch: library %d bytes, binding %d" % (
+            lib.antsrl_cfg_size(), C.sizeof(AntsCfg)))
+    _lib = lib
+    return lib
+
+
+def hip_runtime() -> C.CDLL:
+    """The libamdhip64 this process already uses (torch's), for raw hipEvent_t handling."""
+    load()
+    for line in open("/proc/self/maps"):
+        path = line.split()[-1]
+        if "libamdhip64" in path:
+            return C.CDLL(path)
+    raise AntsrlError("no libamdhip64 mapped in this process")
+
+
+def check(rc: int, what: str = "antsrl") -> None:
+    if rc != 0:
+        msg = load().antsrl_last_error().decode("utf-8", "replace")
+        raise AntsrlError("%s failed (%d): %s" % (what, rc, msg))

@@ -1,0 +1,174 @@
+"""BatchedAntsEnv — E independent AntsRL environments stepped on one MI355X.
+
+Thin host-side plumbing over the C-ABI (include/antsrl.h): PyTorch-ROCm supplies device memory
+(one workspace tensor + the observation / reward / done output tensors) and the stream; every
+piece of arithmetic happens in the HIP kernels of libantsrl_hip.so.  There is no CPU fallback.
+
+Call order mirrors the reference driver (main.py:88-131):
+    env.reset(init); obs, agent_state, _ = env.observe()
+    loop:  obs, agent_state, reward, done = env.step(rotation, pheromone); env.update()
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+from . import config as cfgmod
+from .config import AntsCfg, AntsInit
+
+_STATE_DTYPES = {
+    cfgmod.S_ANTS_XYT: torch.float64, cfgmod.S_PREV_XY: torch.float64, cfgmod.S_HOLDING: torch.float32,
+    cfgmod.S_MANDIBLES: torch.uint8, cfgmod.S_ACTIVATION: torch.float32, cfgmod.S_PHERO: torch.float32,
+    cfgmod.S_FOOD: torch.float32, cfgmod.S_EXPLORED: torch.uint8, cfgmod.S_ANTHILL_FOOD: torch.float64,
+    cfgmod.S_ROCK_CENTERS: torch.float64, cfgmod.S_TIMESTEP: torch.int32, cfgmod.S_REWARD_STATE: torch.uint8,
+    cfgmod.S_WALLS: torch.uint8, cfgmod.S_ANTHILL_AREA: torch.uint8, cfgmod.S_SEED: torch.float32,
+}
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class BatchedAntsEnv:
+    def __init__(self, cfg: AntsCfg, device: Optional[torch.device] = None):
+        if not torch.cuda.is_available():
+            raise _lib.AntsrlError("BatchedAntsEnv needs an MI355X (torch.cuda.is_available() is False); "
+                                   "there is no CPU fallback")
+        self.lib = _lib.load()
+        self.cfg = cfg.copy()
+        self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
+        need = C.c_size_t()
+        _lib.check(self.lib.antsrl_workspace_bytes(C.byref(self.cfg), C.byref(need)), "workspace_bytes")
+        self.workspace_bytes = need.value
+        with torch.cuda.device(self.device):
+            self._ws = torch.empty(need.value + 256, dtype=torch.uint8, device=self.device)
+            off = (-self._ws.data_ptr()) % 256
+            self._ws_ptr = self._ws.data_ptr() + off
+            self._h = C.c_void_p()
+            _lib.check(self.lib.antsrl_create(C.byref(self.cfg), C.c_void_p(self._ws_ptr), need.value,
+                                              C.byref(self._h)), "create")
+            E, N, P, K = cfg.n_envs, cfg.n_ants, cfg.pside, cfg.n_channels
+            self.obs = torch.empty((E, N, P, P, K), dtype=torch.float32, device=self.device)
+            self.agent_state = torch.empty((E, N, 2), dtype=torch.float32, device=self.device)
+            self.reward = torch.empty((E, N), dtype=torch.float32, device=self.device)
+            self.done = torch.zeros((E,), dtype=torch.uint8, device=self.device)
+        self._keep = None
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            self.lib.antsrl_destroy(h)
+            self._h = None
+
+    # ------------------------------------------------------------------ helpers
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _dev(self, a, dtype, shape=None):
+        if a is None:
+            return None
+        t = torch.as_tensor(np.ascontiguousarray(a) if isinstance(a, np.ndarray) else a)
+        t = t.to(device=self.device, dtype=dtype).contiguous()
+        if shape is not None:
+            assert tuple(t.shape) == tuple(shape), "expected shape %s, got %s" % (shape, tuple(t.shape))
+        return t
+
+    # ------------------------------------------------------------------ API
+    def reset(self, init: Dict[str, object]) -> None:
+        """Loads the initial state (EnvironmentGenerator.generate, environment_generator.py:52-106).
+        init: ants_xyt f64[E,N,3], seed f64[E,N], walls u8[E,W,H], food f32[E,W,H],
+        anthill_xyr i32[E,3], rocks f64[E,R,4] (if R>0), optional phero f32[E,C,W,H]."""
+        c = self.cfg
+        E, N, W, H, Cn, R = c.n_envs, c.n_ants, c.w, c.h, c.n_phero, c.n_rocks
+        t = dict(
+            ants_xyt=self._dev(init["ants_xyt"], torch.float64, (E, N, 3)),
+            seed=self._dev(init["seed"], torch.float64, (E, N)),
+            walls=self._dev(init["walls"], torch.uint8, (E, W, H)),
+            food=self._dev(init["food"], torch.float32, (E, W, H)),
+            anthill_xyr=self._dev(init["anthill_xyr"], torch.int32, (E, 3)),
+            rocks=self._dev(init.get("rocks"), torch.float64, (E, R, 4)) if R > 0 else None,
+            phero=self._dev(init.get("phero"), torch.float32, (E, Cn, W, H)),
+        )
+        ai = AntsInit(*[None if t[k] is None else t[k].data_ptr()
+                        for k in ("ants_xyt", "seed", "walls", "food", "anthill_xyr", "rocks", "phero")])
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.antsrl_reset(self._h, C.byref(ai), self._stream()), "reset")
+        self._keep = t  # inputs must outlive the enqueued reset kernels
+
+    def _actions(self, rotation, phero):
+        c = self.cfg
+        rot = self._dev(rotation, torch.int8, (c.n_envs, c.n_ants))
+        ph = self._dev(phero, torch.int8, (c.n_envs, c.n_ants))
+        return rot, ph
+
+    def step(self, rotation, phero, want_obs: bool = True):
+        """RLApi.step (RL_api.py:168-204) for all envs -> (obs, agent_state, reward, done)."""
+        rot, ph = self._actions(rotation, phero)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.antsrl_step(self._h, _ptr(rot), _ptr(ph), _ptr(self.obs if want_obs else None),
+                                            _ptr(self.agent_state), _ptr(self.reward), _ptr(self.done),
+                                            self._stream()), "step")
+        return self.obs, self.agent_state, self.reward, self.done
+
+    def observe(self, want_obs: bool = True):
+        """RLApi.observation (RL_api.py:96-165) -> (obs, agent_state, reward)."""
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.antsrl_observe(self._h, _ptr(self.obs if want_obs else None),
+                                               _ptr(self.agent_state), _ptr(self.reward), self._stream()),
+                       "observe")
+        return self.obs, self.agent_state, self.reward
+
+    def update(self, wall_jitter=None) -> None:
+        """Environment.update (environment.py:42-47)."""
+        c = self.cfg
+        j = self._dev(wall_jitter, torch.float64, (c.n_envs, c.n_ants))
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.antsrl_update(self._h, _ptr(j), self._stream()), "update")
+
+    def step_update(self, rotation, phero, wall_jitter=None, want_obs: bool = True):
+        """main.py:98 + main.py:131 in one call."""
+        c = self.cfg
+        rot, ph = self._actions(rotation, phero)
+        j = self._dev(wall_jitter, torch.float64, (c.n_envs, c.n_ants))
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.antsrl_step_update(self._h, _ptr(rot), _ptr(ph), _ptr(j),
+                                                   _ptr(self.obs if want_obs else None), _ptr(self.agent_state),
+                                                   _ptr(self.reward), _ptr(self.done), self._stream()),
+                       "step_update")
+        return self.obs, self.agent_state, self.reward, self.done
+
+    def set_timing_events(self, events) -> None:
+        """events: sequence of 4 raw hipEvent_t handles (ints) or None; see antsrl_set_timing_events."""
+        if events is None:
+            _lib.check(self.lib.antsrl_set_timing_events(self._h, None), "set_timing_events")
+        else:
+            arr = (C.c_void_p * 4)(*[C.c_void_p(int(e)) for e in events])
+            _lib.check(self.lib.antsrl_set_timing_events(self._h, arr), "set_timing_events")
+
+    def set_activation(self, act, new_deposit_strength: float = 0.0) -> None:
+        """Ants.activate_all_pheromones (ants.py:86-87)."""
+        c = self.cfg
+        a = self._dev(act, torch.float32, (c.n_envs, c.n_ants, c.n_phero))
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.antsrl_set_activation(self._h, _ptr(a), float(new_deposit_strength),
+                                                      self._stream()), "set_activation")
+
+    def read_state(self, which: int) -> torch.Tensor:
+        c = self.cfg
+        E, N, W, H, Cn, R = c.n_envs, c.n_ants, c.w, c.h, c.n_phero, c.n_rocks
+        shapes = {
+            cfgmod.S_ANTS_XYT: (E, N, 3), cfgmod.S_PREV_XY: (E, N, 2), cfgmod.S_HOLDING: (E, N),
+            cfgmod.S_MANDIBLES: (E, N), cfgmod.S_ACTIVATION: (E, N, Cn), cfgmod.S_PHERO: (E, Cn, W, H),
+            cfgmod.S_FOOD: (E, W, H), cfgmod.S_EXPLORED: (E, W, H), cfgmod.S_ANTHILL_FOOD: (E,),
+            cfgmod.S_ROCK_CENTERS: (E, R, 2), cfgmod.S_TIMESTEP: (E,), cfgmod.S_REWARD_STATE: (E, N),
+            cfgmod.S_WALLS: (E, W, H), cfgmod.S_ANTHILL_AREA: (E, W, H), cfgmod.S_SEED: (E, N),
+        }
+        out = torch.empty(shapes[which], dtype=_STATE_DTYPES[which], device=self.device)
+        if out.numel():
+            with torch.cuda.device(self.device):
+                _lib.check(self.lib.antsrl_read_state(self._h, which, _ptr(out), self._stream()), "read_state")
+        return out

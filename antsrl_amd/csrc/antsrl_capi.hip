@@ -1,0 +1,343 @@
+// antsrl_capi.hip — the C-ABI of libantsrl_hip.so (include/antsrl.h).
+//
+// Host-side only: validates the configuration, carves the caller's device workspace into the
+// state arrays of antsrl_device.h, and enqueues the kernels of antsrl_kernels.hip on the
+// caller's stream.  No allocation, no synchronisation, no exceptions across the ABI.
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <new>
+
+#include "antsrl_device.h"
+
+// launchers (antsrl_kernels.hip)
+hipError_t antsrl_launch_act(const KP &p, const int8_t *rot, const int8_t *ph, int cur, float *obs,
+                             float *agent_state, float *reward, uint8_t *done, int flags, hipStream_t st);
+bool antsrl_act_fits(const KP &p);
+hipError_t antsrl_launch_sweep(const KP &p, int cur, hipStream_t st);
+hipError_t antsrl_launch_update(const KP &p, const double *jitter, int out_buf, hipStream_t st);
+hipError_t antsrl_launch_collect_full(const KP &p, hipStream_t st);
+hipError_t antsrl_launch_reset(const KP &p, const AntsInit *in, hipStream_t st);
+hipError_t antsrl_launch_set_activation(const KP &p, const float *act, hipStream_t st);
+hipError_t antsrl_launch_read_state(const KP &p, int which, int cur, void *dst, hipStream_t st);
+
+struct AntsHandle {
+    AntsCfg cfg;
+    KP p;
+    int cur;               // pheromone buffer holding the current grid
+    int steps_since_update;// RLApi.step calls since the last Environment.update
+    bool need_full_collect;// next update must run Anthill.update over the whole grid
+    bool is_reset;
+    size_t ws_bytes;
+    hipEvent_t ev[4];      // measurement hook (antsrl_set_timing_events)
+    bool ev_armed;
+};
+
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+static int hip_fail(hipError_t e, const char *what)
+{
+    return fail(ANTSRL_E_DEVICE, "%s: %s", what, hipGetErrorString(e));
+}
+
+extern "C" int antsrl_abi_version(void) { return ANTSRL_ABI_VERSION; }
+extern "C" size_t antsrl_cfg_size(void) { return sizeof(AntsCfg); }
+extern "C" const char *antsrl_last_error(void) { return g_err; }
+
+static int validate(const AntsCfg *c)
+{
+    if (!c) return fail(ANTSRL_E_INVALID, "cfg is NULL");
+    if (c->abi_version != ANTSRL_ABI_VERSION)
+        return fail(ANTSRL_E_INVALID, "AntsCfg.abi_version %d != library %d", c->abi_version, ANTSRL_ABI_VERSION);
+    if (c->n_envs < 1 || c->n_ants < 1 || c->w < 1 || c->h < 1)
+        return fail(ANTSRL_E_INVALID, "n_envs, n_ants, w, h must be >= 1");
+    if ((long long)c->w * c->h > (1ll << 30)) return fail(ANTSRL_E_INVALID, "grid too large");
+    if (c->n_phero < 1 || c->n_phero > ANTSRL_MAX_PHERO)
+        return fail(ANTSRL_E_INVALID, "n_phero must be in 1..%d", ANTSRL_MAX_PHERO);
+    if (c->n_rocks < 0 || c->n_rocks > 32) return fail(ANTSRL_E_INVALID, "n_rocks must be in 0..32");
+    if (c->perception_radius < 0 || 2 * c->perception_radius + 1 > ANTSRL_MAX_PSIDE)
+        return fail(ANTSRL_E_INVALID, "perception side must be <= %d", ANTSRL_MAX_PSIDE);
+    if (c->n_channels < 1 || c->n_channels > ANTSRL_MAX_CHANNELS)
+        return fail(ANTSRL_E_INVALID, "n_channels must be in 1..%d", ANTSRL_MAX_CHANNELS);
+    for (int k = 0; k < c->n_channels; ++k) {
+        const int kind = c->channel_kind[k];
+        if (kind < ANTSRL_CH_ANTS || kind > ANTSRL_CH_ROCKS) return fail(ANTSRL_E_INVALID, "bad channel kind");
+        if (kind == ANTSRL_CH_PHERO && (c->channel_arg[k] < 0 || c->channel_arg[k] >= c->n_phero))
+            return fail(ANTSRL_E_INVALID, "pheromone channel index out of range");
+        if (kind == ANTSRL_CH_ROCKS && c->n_rocks == 0)
+            return fail(ANTSRL_E_INVALID, "rocks perceived but n_rocks == 0");
+    }
+    if (c->filter_radius < 0 || c->filter_radius > ANTSRL_MAX_FILTER_RADIUS)
+        return fail(ANTSRL_E_INVALID, "filter_radius must be in 0..%d", ANTSRL_MAX_FILTER_RADIUS);
+    if (c->reward_kind < ANTSRL_REWARD_NONE || c->reward_kind > ANTSRL_REWARD_ALL)
+        return fail(ANTSRL_E_INVALID, "bad reward_kind");
+    if (c->has_max_val && !(c->phero_max_val > 0)) return fail(ANTSRL_E_INVALID, "phero_max_val must be > 0");
+    return ANTSRL_OK;
+}
+
+// Carves the workspace; with base == NULL only computes the size.
+static size_t carve(const AntsCfg *c, DState *s, unsigned char *base)
+{
+    const size_t E = c->n_envs, N = c->n_ants, G = (size_t)c->w * c->h, Cn = c->n_phero, R = c->n_rocks;
+    const size_t words = (G + 31) / 32;
+    size_t off = 0;
+    auto take = [&](size_t bytes) -> unsigned char * {
+        unsigned char *ptr = base ? base + off : nullptr;
+        off = (off + bytes + 255) / 256 * 256;
+        return ptr;
+    };
+    DState d;
+    d.x = (double *)take(8 * E * N); d.y = (double *)take(8 * E * N); d.theta = (double *)take(8 * E * N);
+    d.prev_x = (double *)take(8 * E * N); d.prev_y = (double *)take(8 * E * N);
+    d.prev_dist = (double *)take(8 * E * N);
+    d.holding = (float *)take(4 * E * N); d.seed = (float *)take(4 * E * N);
+    d.prev_holding = (float *)take(4 * E * N);
+    d.activation = (float *)take(4 * E * N * Cn);
+    d.mandibles = (uint8_t *)take(E * N); d.reward_state = (uint8_t *)take(E * N);
+    d.dirty_cell = (int32_t *)take(4 * E * N);
+    d.phero[0] = (float *)take(4 * E * G * Cn); d.phero[1] = (float *)take(4 * E * G * Cn);
+    d.food = (float *)take(4 * E * G);
+    d.walls_bits = (uint32_t *)take(4 * E * words); d.area_bits = (uint32_t *)take(4 * E * words);
+    d.explored_bits = (uint32_t *)take(4 * E * words);
+    d.anthill_xyr = (int32_t *)take(4 * E * 3);
+    d.anthill_food = (double *)take(8 * E);
+    d.rock_cx = (double *)take(8 * E * (R ? R : 1)); d.rock_cy = (double *)take(8 * E * (R ? R : 1));
+    d.rock_r = (double *)take(8 * E * (R ? R : 1)); d.rock_w = (double *)take(8 * E * (R ? R : 1));
+    d.timestep = (int32_t *)take(4 * E);
+    d.reward_primed = (uint8_t *)take(E);
+    if (s) *s = d;
+    return off;
+}
+
+static void fill_kp(const AntsCfg *c, KP *p)
+{
+    memset(p, 0, sizeof(*p));
+    p->E = c->n_envs; p->N = c->n_ants; p->W = c->w; p->H = c->h; p->C = c->n_phero; p->R = c->n_rocks;
+    p->K = c->n_channels; p->r = c->perception_radius; p->P = 2 * p->r + 1; p->PP = p->P * p->P;
+    p->words = (int)(((size_t)c->w * c->h + 31) / 32);
+    int ht = 64;
+    while (ht < 2 * c->n_ants) ht <<= 1;
+    p->HT = ht;
+    p->has_mask = c->has_mask; p->has_max_val = c->has_max_val; p->reward_kind = c->reward_kind;
+    p->max_time = c->max_time; p->filter_radius = c->filter_radius;
+    p->explore_on = c->reward_kind == ANTSRL_REWARD_EXPLORATION ||
+                    (c->reward_kind == ANTSRL_REWARD_ALL &&
+                     (c->fct_explore != 0.0 || c->fct_explore_holding != 0.0)); // reward_custom.py:87
+    for (int k = 0; k < ANTSRL_MAX_CHANNELS; ++k) {
+        p->ch_kind[k] = c->channel_kind[k];
+        p->ch_arg[k] = c->channel_arg[k];
+    }
+    memcpy(p->mask, c->mask, ANTSRL_MAX_PCELLS);
+    p->delta = c->delta; p->fwd_delta = c->fwd_delta; p->max_speed = c->max_speed;
+    p->max_rot_speed = c->max_rot_speed; p->carry = c->carry_speed_reduction;
+    p->backward = c->backward_speed_reduction; p->max_hold = c->max_hold;
+    p->max_val = c->phero_max_val; p->deposit_strength = c->deposit_strength;
+    p->threshold = c->phero_threshold; p->reward_threshold = c->reward_threshold;
+    p->fct_explore = c->fct_explore; p->fct_food = c->fct_food; p->fct_anthill = c->fct_anthill;
+    p->fct_explore_holding = c->fct_explore_holding; p->fct_heading = c->fct_headinganthill;
+    memcpy(p->filter, c->filter, sizeof(p->filter));
+    p->rng_seed = c->rng_seed;
+}
+
+extern "C" int antsrl_workspace_bytes(const AntsCfg *cfg, size_t *bytes)
+{
+    int rc = validate(cfg);
+    if (rc) return rc;
+    if (!bytes) return fail(ANTSRL_E_INVALID, "bytes is NULL");
+    *bytes = carve(cfg, nullptr, nullptr);
+    return ANTSRL_OK;
+}
+
+extern "C" int antsrl_create(const AntsCfg *cfg, void *workspace, size_t workspace_bytes, AntsHandle **out)
+{
+    int rc = validate(cfg);
+    if (rc) return rc;
+    if (!out) return fail(ANTSRL_E_INVALID, "out is NULL");
+    if (!workspace) return fail(ANTSRL_E_INVALID, "workspace is NULL");
+    if (((uintptr_t)workspace & 255) != 0) return fail(ANTSRL_E_INVALID, "workspace must be 256-byte aligned");
+    const size_t need = carve(cfg, nullptr, nullptr);
+    if (workspace_bytes < need)
+        return fail(ANTSRL_E_NOMEM, "workspace too small: %zu < %zu bytes", workspace_bytes, need);
+    AntsHandle *h = new (std::nothrow) AntsHandle();
+    if (!h) return fail(ANTSRL_E_NOMEM, "out of host memory");
+    h->cfg = *cfg;
+    fill_kp(cfg, &h->p);
+    carve(cfg, &h->p.s, (unsigned char *)workspace);
+    h->cur = 0; h->steps_since_update = 0; h->need_full_collect = true; h->is_reset = false;
+    h->ws_bytes = need;
+    h->ev_armed = false;
+    if (!antsrl_act_fits(h->p)) {
+        delete h;
+        return fail(ANTSRL_E_UNSUPPORTED,
+                    "grid %dx%d with %d ants needs more than 160 KiB of LDS per workgroup "
+                    "(bit-packed explored/presence maps are kept in LDS)", cfg->w, cfg->h, cfg->n_ants);
+    }
+    *out = h;
+    return ANTSRL_OK;
+}
+
+extern "C" void antsrl_destroy(AntsHandle *h) { delete h; }
+
+extern "C" int antsrl_reset(AntsHandle *h, const AntsInit *init, void *stream)
+{
+    if (!h || !init) return fail(ANTSRL_E_INVALID, "NULL handle or init");
+    if (!init->ants_xyt || !init->seed || !init->walls || !init->food || !init->anthill_xyr)
+        return fail(ANTSRL_E_INVALID, "AntsInit: ants_xyt, seed, walls, food, anthill_xyr are required");
+    if (h->p.R > 0 && !init->rocks) return fail(ANTSRL_E_INVALID, "AntsInit.rocks is NULL but n_rocks > 0");
+    hipError_t e = antsrl_launch_reset(h->p, init, (hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail(e, "reset");
+    h->p.deposit_strength = h->cfg.deposit_strength;
+    h->cur = 0; h->steps_since_update = 0; h->need_full_collect = true; h->is_reset = true;
+    return ANTSRL_OK;
+}
+
+static int not_reset() { return fail(ANTSRL_E_INVALID, "antsrl_reset has not been called on this handle"); }
+
+static int do_step(AntsHandle *h, const int8_t *rot, const int8_t *ph, float *obs, float *agent_state,
+                   float *reward, uint8_t *done, hipStream_t st)
+{
+    if (ph && h->p.C != 2) // Ants.activate_pheromone hard-codes two channels, ants.py:89-96
+        return fail(ANTSRL_E_INVALID, "pheromone actions need exactly 2 pheromone channels (ants.py:89-96)");
+    if (h->steps_since_update > 0) h->need_full_collect = true; // dirty-cell list would be overwritten
+    hipError_t e = antsrl_launch_act(h->p, rot, ph, h->cur, obs, agent_state, reward, done,
+                                     ACT_STEP | (obs ? ACT_HAS_OBS : 0), st);
+    if (e != hipSuccess) return hip_fail(e, "step");
+    h->steps_since_update++;
+    return ANTSRL_OK;
+}
+
+static int do_update(AntsHandle *h, const double *jitter, hipStream_t st, bool sweep_done)
+{
+    hipError_t e;
+    if (!sweep_done) {
+        e = antsrl_launch_sweep(h->p, h->cur, st);
+        if (e != hipSuccess) return hip_fail(e, "pheromone sweep");
+    }
+    e = antsrl_launch_update(h->p, jitter, h->cur ^ 1, st);
+    if (e != hipSuccess) return hip_fail(e, "update");
+    if (h->need_full_collect) {
+        e = antsrl_launch_collect_full(h->p, st);
+        if (e != hipSuccess) return hip_fail(e, "anthill collect");
+        h->need_full_collect = false;
+    }
+    h->cur ^= 1;
+    h->steps_since_update = 0;
+    return ANTSRL_OK;
+}
+
+extern "C" int antsrl_step(AntsHandle *h, const int8_t *rotation, const int8_t *phero, float *obs,
+                           float *agent_state, float *reward, uint8_t *done, void *stream)
+{
+    if (!h) return fail(ANTSRL_E_INVALID, "NULL handle");
+    if (!h->is_reset) return not_reset();
+    if (!agent_state || !reward || !done) return fail(ANTSRL_E_INVALID, "agent_state, reward, done are required");
+    return do_step(h, rotation, phero, obs, agent_state, reward, done, (hipStream_t)stream);
+}
+
+extern "C" int antsrl_observe(AntsHandle *h, float *obs, float *agent_state, float *reward, void *stream)
+{
+    if (!h) return fail(ANTSRL_E_INVALID, "NULL handle");
+    if (!h->is_reset) return not_reset();
+    hipError_t e = antsrl_launch_act(h->p, nullptr, nullptr, h->cur, obs, agent_state, reward, nullptr,
+                                     obs ? ACT_HAS_OBS : 0, (hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail(e, "observe");
+    return ANTSRL_OK;
+}
+
+extern "C" int antsrl_update(AntsHandle *h, const double *wall_jitter, void *stream)
+{
+    if (!h) return fail(ANTSRL_E_INVALID, "NULL handle");
+    if (!h->is_reset) return not_reset();
+    return do_update(h, wall_jitter, (hipStream_t)stream, false);
+}
+
+extern "C" int antsrl_step_update(AntsHandle *h, const int8_t *rotation, const int8_t *phero,
+                                  const double *wall_jitter, float *obs, float *agent_state, float *reward,
+                                  uint8_t *done, void *stream)
+{
+    if (!h) return fail(ANTSRL_E_INVALID, "NULL handle");
+    if (!h->is_reset) return not_reset();
+    if (!agent_state || !reward || !done) return fail(ANTSRL_E_INVALID, "agent_state, reward, done are required");
+    hipStream_t st = (hipStream_t)stream;
+    const bool timed = h->ev_armed;
+    h->ev_armed = false;
+    if (timed) (void)hipEventRecord(h->ev[0], st);
+    // The sweep only reads phero[cur] and the wall bitmap, so it can be enqueued first: the
+    // perception gather of the step reads the same (pre-update) buffer.
+    hipError_t e = antsrl_launch_sweep(h->p, h->cur, st);
+    if (e != hipSuccess) return hip_fail(e, "pheromone sweep");
+    if (timed) (void)hipEventRecord(h->ev[1], st);
+    int rc = do_step(h, rotation, phero, obs, agent_state, reward, done, st);
+    if (rc) return rc;
+    if (timed) (void)hipEventRecord(h->ev[2], st);
+    rc = do_update(h, wall_jitter, st, true);
+    if (timed) (void)hipEventRecord(h->ev[3], st);
+    return rc;
+}
+
+extern "C" int antsrl_set_timing_events(AntsHandle *h, void *const *events)
+{
+    if (!h) return fail(ANTSRL_E_INVALID, "NULL handle");
+    h->ev_armed = events != nullptr;
+    if (events)
+        for (int i = 0; i < 4; ++i) h->ev[i] = (hipEvent_t)events[i];
+    return ANTSRL_OK;
+}
+
+extern "C" int antsrl_set_activation(AntsHandle *h, const float *act, double new_deposit_strength, void *stream)
+{
+    if (!h || !act) return fail(ANTSRL_E_INVALID, "NULL handle or act");
+    if (!h->is_reset) return not_reset();
+    hipError_t e = antsrl_launch_set_activation(h->p, act, (hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail(e, "set_activation");
+    if (new_deposit_strength > 0) h->p.deposit_strength = new_deposit_strength;
+    return ANTSRL_OK;
+}
+
+static size_t state_bytes(const AntsHandle *h, int which)
+{
+    const size_t E = h->p.E, N = h->p.N, G = (size_t)h->p.W * h->p.H, C = h->p.C, R = h->p.R;
+    switch (which) {
+    case ANTSRL_S_ANTS_XYT: return 8 * E * N * 3;
+    case ANTSRL_S_PREV_XY: return 8 * E * N * 2;
+    case ANTSRL_S_HOLDING: case ANTSRL_S_SEED: return 4 * E * N;
+    case ANTSRL_S_MANDIBLES: case ANTSRL_S_REWARD_STATE: return E * N;
+    case ANTSRL_S_ACTIVATION: return 4 * E * N * C;
+    case ANTSRL_S_PHERO: return 4 * E * C * G;
+    case ANTSRL_S_FOOD: return 4 * E * G;
+    case ANTSRL_S_EXPLORED: case ANTSRL_S_WALLS: case ANTSRL_S_ANTHILL_AREA: return E * G;
+    case ANTSRL_S_ANTHILL_FOOD: return 8 * E;
+    case ANTSRL_S_ROCK_CENTERS: return 8 * E * R * 2;
+    case ANTSRL_S_TIMESTEP: return 4 * E;
+    default: return 0;
+    }
+}
+
+extern "C" int antsrl_state_bytes(const AntsHandle *h, int which, size_t *bytes)
+{
+    if (!h || !bytes) return fail(ANTSRL_E_INVALID, "NULL handle or bytes");
+    if (which < 0 || which >= ANTSRL_S_COUNT_) return fail(ANTSRL_E_INVALID, "bad state selector %d", which);
+    *bytes = state_bytes(h, which);
+    return ANTSRL_OK;
+}
+
+extern "C" int antsrl_read_state(AntsHandle *h, int which, void *dst, void *stream)
+{
+    if (!h || !dst) return fail(ANTSRL_E_INVALID, "NULL handle or dst");
+    if (!h->is_reset) return not_reset();
+    if (which < 0 || which >= ANTSRL_S_COUNT_) return fail(ANTSRL_E_INVALID, "bad state selector %d", which);
+    if (state_bytes(h, which) == 0) return ANTSRL_OK;
+    hipError_t e = antsrl_launch_read_state(h->p, which, h->cur, dst, (hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail(e, "read_state");
+    return ANTSRL_OK;
+}

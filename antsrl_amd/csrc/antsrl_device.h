@@ -1,0 +1,54 @@
+// antsrl_device.h — device-side state layout and kernel parameter block (gfx950 only).
+//
+// Data layout in HBM (one batch of E environments, everything env-major):
+//   ants        struct-of-arrays, float64 kinematics: x[E][N], y[E][N], theta[E][N],
+//               prev_x, prev_y (Ants.ants / Ants.prev_ants, environment/ants.py:27,30);
+//               holding f32, mandibles u8, seed f32, activation f32 [E][N][C]
+//   pheromone   f32, channels INTERLEAVED per cell: phero[buf][E][W][H][C], two buffers
+//               (ping-pong: the decay/diffuse sweep reads `cur`, writes `cur^1`, then the
+//               deposit lands in `cur^1`).  One 8-byte gather returns both channels of a cell.
+//   food        f32 [E][W][H]
+//   walls / anthill area / explored map   bit-packed, 1 bit per cell: u32 [E][ceil(W*H/32)],
+//               bit index = x*H + y.  8 KiB per env at 256x256, so whole maps fit in LDS.
+//   rocks       float64 SoA [E][R]
+#pragma once
+#include <stdint.h>
+#include "../../include/antsrl.h"
+
+struct DState {
+    double *x, *y, *theta, *prev_x, *prev_y; // [E*N]
+    double *prev_dist;                       // [E*N]  All_Rewards.previous_dist
+    float *holding, *seed, *prev_holding;    // [E*N]
+    float *activation;                       // [E*N*C]
+    uint8_t *mandibles, *reward_state;       // [E*N]
+    int32_t *dirty_cell;                     // [E*N]  food cell on the anthill area this ant
+                                             //        rewrote in the last step, else -1
+    float *phero[2];                         // [E*G*C] each
+    float *food;                             // [E*G]
+    uint32_t *walls_bits, *area_bits, *explored_bits; // [E*words]
+    int32_t *anthill_xyr;                    // [E*3]
+    double *anthill_food;                    // [E]
+    double *rock_cx, *rock_cy, *rock_r, *rock_w; // [E*R]
+    int32_t *timestep;                       // [E]
+    uint8_t *reward_primed;                  // [E]
+};
+
+// Kernel parameter block, passed by value (lives in the kernarg segment; every field is
+// wave-uniform so the compiler reads it with scalar loads).
+struct KP {
+    DState s;
+    int32_t E, N, W, H, C, R, K, P, PP, r, words;
+    int32_t HT;          // last-writer-wins hash table size (pow2 >= 2N)
+    int32_t has_mask, has_max_val, reward_kind, max_time, filter_radius, explore_on;
+    int32_t ch_kind[ANTSRL_MAX_CHANNELS], ch_arg[ANTSRL_MAX_CHANNELS];
+    uint8_t mask[ANTSRL_MAX_PCELLS + 7];
+    double delta, fwd_delta, max_speed, max_rot_speed, carry, backward, max_hold;
+    double max_val, deposit_strength, threshold, reward_threshold;
+    double fct_explore, fct_food, fct_anthill, fct_explore_holding, fct_heading;
+    double filter[ANTSRL_MAX_FILTER_TAPS];
+    uint64_t rng_seed;
+};
+
+// k_act flags
+#define ACT_STEP 1        // run RLApi.step's action phases before observing
+#define ACT_HAS_OBS 2     // obs pointer valid

@@ -1,0 +1,1067 @@
+// antsrl_kernels.hip — hand-written HIP kernels for gfx950 (MI355X), wave64.
+//
+// One simulation step (RLApi.step + Environment.update of the reference) is three launches:
+//   k_sweep0 / k_sweep_tiled   pheromone decay / diffuse / threshold / wall-zero / clip,
+//                              phero[cur] -> phero[cur^1]          (HBM streaming, the bulk)
+//   k_act                      one workgroup per environment: mandibles + food exchange,
+//                              activation, rotate, move, 7x7 perception gather, reward
+//   k_update                   one workgroup per environment: wall revert + jitter, rock
+//                              push, prev:=cur, pheromone deposit, anthill collect
+// No MFMA anywhere: nothing on this path is a dense contraction.  Compile with
+// -ffp-contract=off (numpy rounds every product before adding).
+//
+// Reference citations are relative to the reference checkout (environment/...).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "antsrl_device.h"
+
+#define WAVE 64
+#define PI_D 3.141592653589793
+#define HASH_EMPTY 0xFFFFFFFFu
+
+// ------------------------------------------------------------------ small helpers
+__device__ __forceinline__ double np_mod_d(double a, double b)
+{
+    // np.mod on float64 (python sign convention), ants.py:63,70-71
+    double r = fmod(a, b);
+    if (r != 0.0) {
+        if ((b < 0) != (r < 0)) r += b;
+    } else {
+        r = copysign(0.0, b);
+    }
+    return r;
+}
+
+__device__ __forceinline__ double warp_coord(double v, double size)
+{
+    // Ants.warp_xy, ants.py:69-71; the single value `size` (np.mod(-1e-17, W) == W, where
+    // the reference raises IndexError) maps to 0 — same convention as the oracle.
+    double r = np_mod_d(v, size);
+    if (r >= size) r = 0.0;
+    return r;
+}
+
+__device__ __forceinline__ int wrap_index(int v, int n)
+{
+    if (v < 0 || v >= n) {
+        v %= n;
+        if (v < 0) v += n;
+    }
+    return v;
+}
+
+__device__ __forceinline__ bool test_bit(const uint32_t *bits, uint32_t cell)
+{
+    return (bits[cell >> 5] >> (cell & 31)) & 1u;
+}
+
+__device__ __forceinline__ uint64_t mix64(uint64_t z)
+{
+    z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ULL;
+    z ^= z >> 27; z *= 0x94D049BB133111EBULL;
+    z ^= z >> 31;
+    return z;
+}
+
+// Counter-based uniform [0,1): same specification as oracle_jitter_u01 (integer-exact).
+__device__ __forceinline__ double jitter_u01(uint64_t seed, uint32_t env, uint32_t timestep, uint32_t ant)
+{
+    uint64_t k = mix64(seed + 0x9E3779B97F4A7C15ULL * ((uint64_t)env + 1));
+    k = mix64(k ^ (0xD1B54A32D192ED03ULL * ((uint64_t)timestep + 1)));
+    k = mix64(k + 0x9E3779B97F4A7C15ULL * ((uint64_t)ant + 1));
+    return (double)(k >> 11) * (1.0 / 9007199254740992.0);
+}
+
+// ---- last-writer-wins resolution --------------------------------------------------
+// numpy's `a[idx] += v` with repeated indices keeps only the LAST ant's update
+// (pheromone.py:39, ants.py:116).  Deterministic regardless of wave scheduling: an LDS
+// open-addressing table maps cell -> highest ant index standing on it.
+__device__ __forceinline__ uint32_t lww_hash(uint32_t cell, uint32_t mask)
+{
+    return (cell * 2654435761u >> 7) & mask;
+}
+
+__device__ __forceinline__ void lww_insert(uint32_t *keys, uint32_t *vals, uint32_t mask, uint32_t cell,
+                                           uint32_t ant)
+{
+    uint32_t h = lww_hash(cell, mask);
+    for (;;) {
+        uint32_t k = atomicCAS(&keys[h], HASH_EMPTY, cell);
+        if (k == HASH_EMPTY || k == cell) {
+            atomicMax(&vals[h], ant);
+            return;
+        }
+        h = (h + 1) & mask;
+    }
+}
+
+__device__ __forceinline__ uint32_t lww_winner(const uint32_t *keys, const uint32_t *vals, uint32_t mask,
+                                               uint32_t cell)
+{
+    uint32_t h = lww_hash(cell, mask);
+    while (keys[h] != cell) h = (h + 1) & mask;
+    return vals[h];
+}
+
+__device__ __forceinline__ void wave_lds_sync()
+{
+    // LDS hand-off between lanes of ONE wave: make the writes visible, keep the compiler
+    // from moving LDS accesses across this point.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+__host__ __device__ __forceinline__ size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// ===================================================================================
+// k_act — RLApi.step (RL_api.py:168-204) / RLApi.observation (RL_api.py:96-165)
+// one workgroup per environment
+// ===================================================================================
+struct ActLds {
+    double *f_cx, *f_cy, *f_ct, *f_st; // [N] per-ant perception frame (centre, cos, sin)
+    double *t_px, *t_py;               // [PP] rotated-grid offsets, RL_api.py:92-93
+    uint32_t *cnt;                     // [N] unexplored-cell count / temp cell index
+    uint32_t *rockmask;                // [N] rocks that can touch the ant's patch
+    uint32_t *b_pres, *b_old, *b_new;  // [words] presence / explored (pre-step) / explored (marked)
+    uint32_t *b_walls, *b_area;        // [words] (only when STATIC_LDS)
+    uint8_t *t_mask;                   // [PP]
+    uint32_t *hkeys, *hvals;           // [HT] — aliases `stage`
+    float *stage;                      // [nwaves*64*K]
+};
+
+__host__ __device__ inline size_t act_lds_bytes(int N, int PP, int words, int HT, int K, int nwaves,
+                                                bool static_lds, ActLds *o, unsigned char *base)
+{
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        size_t at = off;
+        off = (off + bytes + 15) / 16 * 16;
+        return at;
+    };
+    size_t a_cx = take(8 * (size_t)N), a_cy = take(8 * (size_t)N), a_ct = take(8 * (size_t)N),
+           a_st = take(8 * (size_t)N);
+    size_t a_px = take(8 * (size_t)PP), a_py = take(8 * (size_t)PP);
+    size_t a_cnt = take(4 * (size_t)N), a_rm = take(4 * (size_t)N);
+    size_t a_pres = take(4 * (size_t)words), a_old = take(4 * (size_t)words), a_new = take(4 * (size_t)words);
+    size_t a_w = 0, a_a = 0;
+    if (static_lds) {
+        a_w = take(4 * (size_t)words);
+        a_a = take(4 * (size_t)words);
+    }
+    size_t a_mask = take((size_t)PP);
+    size_t hash_b = 8 * (size_t)HT, stage_b = 4 * (size_t)nwaves * 64 * K;
+    size_t a_u = take(hash_b > stage_b ? hash_b : stage_b);
+    if (o) {
+        o->f_cx = (double *)(base + a_cx); o->f_cy = (double *)(base + a_cy);
+        o->f_ct = (double *)(base + a_ct); o->f_st = (double *)(base + a_st);
+        o->t_px = (double *)(base + a_px); o->t_py = (double *)(base + a_py);
+        o->cnt = (uint32_t *)(base + a_cnt); o->rockmask = (uint32_t *)(base + a_rm);
+        o->b_pres = (uint32_t *)(base + a_pres); o->b_old = (uint32_t *)(base + a_old);
+        o->b_new = (uint32_t *)(base + a_new);
+        o->b_walls = (uint32_t *)(base + a_w); o->b_area = (uint32_t *)(base + a_a);
+        o->t_mask = base + a_mask;
+        o->hkeys = (uint32_t *)(base + a_u); o->hvals = o->hkeys + HT;
+        o->stage = (float *)(base + a_u);
+    }
+    return off;
+}
+
+template <int C, bool STATIC_LDS>
+__global__ void __launch_bounds__(1024)
+k_act(const KP p, const int8_t *__restrict__ rotation, const int8_t *__restrict__ phero_act, const int cur,
+      float *__restrict__ obs, float *__restrict__ agent_state, float *__restrict__ reward,
+      uint8_t *__restrict__ done, const int flags)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int e = blockIdx.x, tid = threadIdx.x, T = blockDim.x;
+    const int lane = tid & 63, wave = tid >> 6, nwaves = T >> 6;
+    const int N = p.N, W = p.W, H = p.H, K = p.K, P = p.P, PP = p.PP, R = p.R;
+    const size_t G = (size_t)W * H;
+    ActLds L;
+    act_lds_bytes(N, PP, p.words, p.HT, K, nwaves, STATIC_LDS, &L, smem);
+
+    const size_t eN = (size_t)e * N;
+    const uint32_t *g_walls = p.s.walls_bits + (size_t)e * p.words;
+    const uint32_t *g_area = p.s.area_bits + (size_t)e * p.words;
+    uint32_t *g_expl = p.s.explored_bits + (size_t)e * p.words;
+    const uint32_t *walls = STATIC_LDS ? L.b_walls : g_walls;
+    const uint32_t *area = STATIC_LDS ? L.b_area : g_area;
+    float *food = p.s.food + (size_t)e * G;
+    const float *ph = p.s.phero[cur] + (size_t)e * G * C;
+    const bool do_step = flags & ACT_STEP;
+    const bool explore = p.explore_on != 0;
+    const uint8_t primed0 = p.s.reward_primed[e];
+
+    // ---- phase 0: stage bitmaps and tables in LDS
+    for (int w = tid; w < p.words; w += T) {
+        uint32_t ex = g_expl[w];
+        L.b_pres[w] = 0u;
+        L.b_old[w] = ex;
+        L.b_new[w] = ex;
+        if (STATIC_LDS) {
+            L.b_walls[w] = g_walls[w];
+            L.b_area[w] = g_area[w];
+        }
+    }
+    for (int q = tid; q < PP; q += T) {
+        int a = q / P, b = q % P;
+        L.t_px[q] = (double)(b - p.r) * p.delta; // coords[a][b] = (arange[b], arange[a]) * DELTA
+        L.t_py[q] = (double)(a - p.r) * p.delta;
+        L.t_mask[q] = p.has_mask ? p.mask[q] : (uint8_t)1;
+    }
+    if (do_step)
+        for (int h = tid; h < p.HT; h += T) {
+            L.hkeys[h] = HASH_EMPTY;
+            L.hvals[h] = 0u;
+        }
+    __syncthreads();
+
+    if (do_step) {
+        // ---- phase 1a: mandible target (RL_api.py:178-185) + Ants.update_mandibles reads
+        //      (ants.py:102-114).  All food reads happen before any food write.
+        for (int i = tid; i < N; i += T) {
+            const double x = p.s.x[eN + i], y = p.s.y[eN + i];
+            const uint32_t cprev = (uint32_t)((int)p.s.prev_x[eN + i] * H + (int)p.s.prev_y[eN + i]);
+            const uint32_t ccur = (uint32_t)((int)x * H + (int)y);
+            const float q = food[cprev];
+            const int old_m = p.s.mandibles[eN + i];
+            int m = old_m;
+            for (int k = 0; k < K; ++k) { // perceived_objects order matters
+                if (p.ch_kind[k] == ANTSRL_CH_FOOD) m = (q > 0.0f) | m;                      // :182
+                else if (p.ch_kind[k] == ANTSRL_CH_ANTHILL) m = (1 - (int)test_bit(area, ccur)) & m; // :184
+            }
+            const int closing = m & (1 - old_m), opening = (1 - m) & old_m; // ants.py:103-104
+            const float hold = p.s.holding[eN + i];
+            const float taken = fminf((float)p.max_hold, fmaxf(0.0f, q)) * (float)closing; // :111
+            const float dropped = hold * (float)opening;                                    // :114
+            p.s.holding[eN + i] = hold + (taken - dropped);                                 // :117
+            p.s.mandibles[eN + i] = (uint8_t)m;                                             // :107
+            // stash for phase 1b (frame arrays are free until phase 2)
+            L.cnt[i] = cprev;
+            ((float *)L.f_cx)[i] = q;
+            ((float *)L.f_cy)[i] = dropped - taken;
+            lww_insert(L.hkeys, L.hvals, (uint32_t)p.HT - 1, cprev, (uint32_t)i);
+        }
+        __syncthreads();
+        // ---- phase 1b: ants.py:116 `qte[cell] += dropped - taken`, last ant on a cell wins
+        for (int i = tid; i < N; i += T) {
+            const uint32_t cprev = L.cnt[i];
+            const float delta = ((float *)L.f_cy)[i];
+            int32_t dirty = -1;
+            if (delta != 0.0f && lww_winner(L.hkeys, L.hvals, (uint32_t)p.HT - 1, cprev) == (uint32_t)i) {
+                food[cprev] = ((float *)L.f_cx)[i] + delta;
+                if (test_bit(area, cprev)) dirty = (int32_t)cprev;
+            }
+            p.s.dirty_cell[eN + i] = dirty;
+        }
+        __syncthreads();
+    }
+
+    // ---- phase 2: activation, rotate, move (RL_api.py:187-196) and the perception frame
+    const double margin = (double)p.r * p.delta * 1.4142135623730951 + 1.5;
+    for (int i = tid; i < N; i += T) {
+        double x = p.s.x[eN + i], y = p.s.y[eN + i], th = p.s.theta[eN + i];
+        if (do_step) {
+            if (phero_act) { // Ants.activate_pheromone, ants.py:89-96
+                const int a = phero_act[eN + i];
+                float a0 = 0.0f, a1 = 0.0f;
+                if (a == 1) a0 = (float)p.deposit_strength;
+                else if (a != 0) a1 = (float)p.deposit_strength;
+                p.s.activation[(eN + i) * C + 0] = a0;
+                if (C > 1) p.s.activation[(eN + i) * C + 1] = a1;
+            }
+            if (rotation) // Ants.rotate_ants + warp_theta, ants.py:62-67
+                th = np_mod_d(th + (double)rotation[eN + i] * p.max_rot_speed, 2 * PI_D);
+        }
+        double sn, cs;
+        sincos(th, &sn, &cs);
+        if (do_step) {
+            // RL_api.py:194-196, Ants.forward_ants ants.py:77-80
+            double fwd = 1.0 * p.max_speed * (1 - (double)p.s.holding[eN + i] * p.carry);
+            if (fwd < 0) fwd *= p.backward;
+            x = warp_coord(x + cs * fwd, (double)W);
+            y = warp_coord(y + sn * fwd, (double)H);
+            p.s.x[eN + i] = x;
+            p.s.y[eN + i] = y;
+            p.s.theta[eN + i] = th;
+        }
+        // RL_api.py:100-108
+        double xf = x, yf = y;
+        if (p.fwd_delta != 0.0) {
+            xf += cs * p.fwd_delta;
+            yf += sn * p.fwd_delta;
+        }
+        double st, ct;
+        sincos(th + PI_D * 0.5, &st, &ct);
+        L.f_cx[i] = xf; L.f_cy[i] = yf; L.f_ct[i] = ct; L.f_st[i] = st;
+        L.cnt[i] = 0u;
+        // presence map, RL_api.py:137-141 (0/1, not a count)
+        const uint32_t cell = (uint32_t)(wrap_index((int)x, W) * H + wrap_index((int)y, H));
+        atomicOr(&L.b_pres[cell >> 5], 1u << (cell & 31));
+        // rocks whose disc can reach this ant's patch (conservative; exact test per cell)
+        uint32_t rm = 0u;
+        if (R > 0) {
+            const bool border = xf - margin < 0 || yf - margin < 0 || xf + margin >= W || yf + margin >= H;
+            for (int q = 0; q < R; ++q) {
+                const double dx = p.s.rock_cx[(size_t)e * R + q] - xf, dy = p.s.rock_cy[(size_t)e * R + q] - yf;
+                const double rr = p.s.rock_r[(size_t)e * R + q] + margin;
+                if (border || dx * dx + dy * dy < rr * rr) rm |= 1u << q;
+            }
+        }
+        L.rockmask[i] = rm;
+    }
+    __syncthreads();
+
+    // ---- phase 3: perception gather, RL_api.py:109-148.  Work item = (ant, cell); a wave
+    //      takes 64 consecutive items, stages its 64*K outputs in LDS and writes them as one
+    //      contiguous, 16-byte-vectorised run of the observation tensor.
+    const uint32_t total = (uint32_t)N * (uint32_t)PP;
+    float *stage = L.stage + (size_t)wave * 64 * K;
+    float *obs_env = (flags & ACT_HAS_OBS) ? obs + (size_t)e * total * K : nullptr;
+    const bool vec_ok = (((size_t)total * K) % 4 == 0);
+    const float inv_dummy = 0.0f;
+    (void)inv_dummy;
+    for (uint32_t base = (uint32_t)wave * 64; base < total; base += (uint32_t)nwaves * 64) {
+        const uint32_t item = base + lane;
+        if (item < total) {
+            const uint32_t i = item / (uint32_t)PP, q = item - i * (uint32_t)PP;
+            const double px = L.t_px[q], py = L.t_py[q];
+            const double ct = L.f_ct[i], st = L.f_st[i];
+            const double rx = ct * px - st * py; // RL_api.py:110-111
+            const double ry = st * px + ct * py;
+            const int ix = wrap_index((int)rint(rx + L.f_cx[i]), W); // :114-119
+            const int iy = wrap_index((int)rint(ry + L.f_cy[i]), H);
+            const uint32_t cell = (uint32_t)(ix * H + iy);
+            if (explore && !test_bit(L.b_old, cell)) { // reward_custom.py:19,22 (mask ignored)
+                atomicAdd(&L.cnt[i], 1u);
+                atomicOr(&L.b_new[cell >> 5], 1u << (cell & 31));
+            }
+            if (obs_env) {
+                float *o = stage + lane * K;
+                if (!L.t_mask[q]) { // RL_api.py:147-148: mask*(p+1)-1 == -1
+                    for (int k = 0; k < K; ++k) o[k] = -1.0f;
+                } else {
+                    float pv[C];
+                    bool have_ph = false;
+                    for (int k = 0; k < K; ++k) {
+                        float v = 0.0f;
+                        switch (p.ch_kind[k]) {
+                        case ANTSRL_CH_PHERO: // :124-125
+                            if (!have_ph) {
+                                if (C == 2) {
+                                    const float2 t = *reinterpret_cast<const float2 *>(ph + (size_t)cell * 2);
+                                    pv[0] = t.x; pv[C - 1] = t.y;
+                                } else {
+                                    for (int c = 0; c < C; ++c) pv[c] = ph[(size_t)cell * C + c];
+                                }
+                                have_ph = true;
+                            }
+                            {
+                                float t = pv[0];
+                                for (int c = 1; c < C; ++c) t = (p.ch_arg[k] == c) ? pv[c] : t;
+                                v = t / (float)p.max_val;
+                            }
+                            break;
+                        case ANTSRL_CH_FOOD: v = food[cell]; break;                          // :126-127
+                        case ANTSRL_CH_WALLS: v = test_bit(walls, cell) ? 1.0f : 0.0f; break;  // :128-129
+                        case ANTSRL_CH_ANTHILL: v = test_bit(area, cell) ? 1.0f : 0.0f; break; // :130-131
+                        case ANTSRL_CH_ANTS: v = test_bit(L.b_pres, cell) ? 1.0f : 0.0f; break; // :142
+                        case ANTSRL_CH_ROCKS: {                                               // :132-135
+                            uint32_t rm = L.rockmask[i];
+                            bool any = false;
+                            while (rm) {
+                                const int r = __builtin_ctz(rm);
+                                rm &= rm - 1;
+                                const double vx = (double)ix - p.s.rock_cx[(size_t)e * R + r];
+                                const double vy = (double)iy - p.s.rock_cy[(size_t)e * R + r];
+                                any |= sqrt(vx * vx + vy * vy) < p.s.rock_r[(size_t)e * R + r];
+                            }
+                            v = any ? 1.0f : 0.0f;
+                        } break;
+                        default: break;
+                        }
+                        o[k] = v;
+                    }
+                }
+            }
+        }
+        if (obs_env) {
+            wave_lds_sync();
+            const uint32_t nvalid = min(64u, total - base);
+            const uint32_t nfl = nvalid * (uint32_t)K;
+            float *dst = obs_env + (size_t)base * K;
+            if (vec_ok) { // base*K*4 is a multiple of 256 bytes; env base is 16-byte aligned
+                const uint32_t n4 = nfl >> 2;
+                for (uint32_t j = lane; j < n4; j += 64)
+                    reinterpret_cast<float4 *>(dst)[j] = reinterpret_cast<const float4 *>(stage)[j];
+                for (uint32_t j = (n4 << 2) + lane; j < nfl; j += 64) dst[j] = stage[j];
+            } else {
+                for (uint32_t j = lane; j < nfl; j += 64) dst[j] = stage[j];
+            }
+            wave_lds_sync();
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 4: agent_state (RL_api.py:160-162), reward.observation hooks, give_reward
+    for (int i = tid; i < N; i += T) {
+        const float hold = p.s.holding[eN + i];
+        if (agent_state) {
+            agent_state[(eN + i) * 2 + 0] = hold;
+            agent_state[(eN + i) * 2 + 1] = p.s.seed[eN + i];
+        }
+        double rw = 0.0;
+        if (p.reward_kind != ANTSRL_REWARD_NONE) {
+            // first observation after Reward.setup sees delta-holding == 0 (alias quirk,
+            // reward_custom.py:35,68 — see oracle/antsrl_oracle.c)
+            const float prev_h = primed0 ? p.s.prev_holding[eN + i] : hold;
+            const double dh = (double)hold - (double)prev_h;
+            if (p.reward_kind == ANTSRL_REWARD_EXPLORATION) {
+                rw = (double)L.cnt[i] / 10.0; // reward_custom.py:19
+            } else if (p.reward_kind == ANTSRL_REWARD_FOOD) {
+                rw = dh < 0 ? 10.0 : dh; // reward_custom.py:38-39
+                p.s.prev_holding[eN + i] = hold;
+            } else { // All_Rewards, reward_custom.py:79-106
+                const double r_food = dh < 0 ? 0.0 : dh;
+                const double r_anthill = dh < 0 ? 1.0 : 0.0;
+                p.s.prev_holding[eN + i] = hold;
+                if (explore) {
+                    double re = (double)L.cnt[i] / 10.0;
+                    re = (hold == 0.0f) ? re * p.fct_explore : re * p.fct_explore_holding;
+                    rw += re;
+                }
+                const double dx = p.s.x[eN + i] - (double)p.s.anthill_xyr[3 * e + 0];
+                const double dy = p.s.y[eN + i] - (double)p.s.anthill_xyr[3 * e + 1];
+                const double nd = sqrt(dx * dx + dy * dy);
+                const double heading = (double)((p.s.prev_dist[eN + i] > nd) && (hold > 0.0f)) * 0.1;
+                p.s.prev_dist[eN + i] = nd;
+                rw += r_food * p.fct_food + r_anthill * p.fct_anthill + heading * p.fct_heading;
+            }
+        }
+        if (reward) reward[eN + i] = (float)rw;
+        if (do_step && rw - p.reward_threshold > 0) p.s.reward_state[eN + i] = 255; // ants.py:119-121
+    }
+    if (explore)
+        for (int w = tid; w < p.words; w += T) g_expl[w] = L.b_new[w];
+    if (tid == 0) {
+        if (p.reward_kind != ANTSRL_REWARD_NONE) p.s.reward_primed[e] = 1;
+        if (do_step && done) done[e] = (uint8_t)(p.max_time == p.s.timestep[e]); // RL_api.py:200
+    }
+}
+
+// ===================================================================================
+// k_update — Environment.update minus the pheromone sweep (environment.py:42-47):
+// Walls (walls.py:22-28), CircleObstacles (circle_obstacles.py:32-58), Ants.update
+// (ants.py:123-130), Anthill.update (anthill.py:41-46, sparse form).
+// one workgroup per environment; `out_buf` = pheromone buffer the sweep just wrote.
+// ===================================================================================
+__device__ __forceinline__ uint32_t block_excl_scan_flag(bool flag, uint32_t *wave_tot, int lane, int wave,
+                                                         int nwaves, uint32_t *block_total)
+{
+    const unsigned long long m = __ballot(flag);
+    const uint32_t in_wave = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) wave_tot[wave] = (uint32_t)__popcll(m);
+    __syncthreads();
+    uint32_t off = 0, tot = 0;
+    for (int w = 0; w < nwaves; ++w) {
+        const uint32_t t = wave_tot[w];
+        if (w < wave) off += t;
+        tot += t;
+    }
+    __syncthreads();
+    *block_total = tot;
+    return off + in_wave;
+}
+
+template <int C>
+__global__ void __launch_bounds__(1024)
+k_update(const KP p, const double *__restrict__ wall_jitter, const int out_buf)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int e = blockIdx.x, tid = threadIdx.x, T = blockDim.x;
+    const int lane = tid & 63, wave = tid >> 6, nwaves = T >> 6;
+    const int N = p.N, W = p.W, H = p.H, R = p.R;
+    const size_t G = (size_t)W * H, eN = (size_t)e * N;
+    uint32_t *hkeys = (uint32_t *)smem, *hvals = hkeys + p.HT;
+    double *rk = (double *)(smem + align_up(8 * (size_t)p.HT, 16)); // [2R] new rock centres
+    double *red = rk + 2 * (R > 0 ? R : 1);                          // [nwaves] reduction scratch
+    uint32_t *wave_tot = (uint32_t *)(red + nwaves);                 // [nwaves]
+
+    const uint32_t *walls = p.s.walls_bits + (size_t)e * p.words;
+    float *food = p.s.food + (size_t)e * G;
+    float *out = p.s.phero[out_buf] + (size_t)e * G * C;
+    const int ts = p.s.timestep[e] + 1; // environment.py:45
+
+    for (int h = tid; h < p.HT; h += T) {
+        hkeys[h] = HASH_EMPTY;
+        hvals[h] = 0u;
+    }
+
+    // ---- Walls.update, walls.py:25-28
+    uint32_t carry = 0;
+    for (int base = 0; base < N; base += T) {
+        const int i = base + tid;
+        bool hit = false;
+        if (i < N) hit = test_bit(walls, (uint32_t)((int)p.s.x[eN + i] * H + (int)p.s.y[eN + i]));
+        double u = 0.0;
+        if (wall_jitter) { // k-th colliding ant (index order) takes the k-th draw
+            uint32_t tot;
+            const uint32_t rank = carry + block_excl_scan_flag(hit, wave_tot, lane, wave, nwaves, &tot);
+            carry += tot;
+            if (hit) u = wall_jitter[eN + rank];
+        } else if (hit) {
+            u = jitter_u01(p.rng_seed, (uint32_t)e, (uint32_t)ts, (uint32_t)i);
+        }
+        if (hit) {
+            p.s.x[eN + i] = p.s.prev_x[eN + i];
+            p.s.y[eN + i] = p.s.prev_y[eN + i];
+            p.s.theta[eN + i] += u - 0.5; // theta is NOT re-wrapped here
+        }
+    }
+    __syncthreads();
+
+    // ---- CircleObstacles.update, circle_obstacles.py:35-58
+    if (R > 0) {
+        // pass 1: centres -= sum_over_ants(push)/weight.  numpy sums the ants sequentially in
+        // index order; non-colliding ants contribute exact zeros, so adding only the
+        // colliding ones in index order reproduces the float64 result bit for bit.
+        for (int q = wave; q < R; q += nwaves) {
+            const double cx = p.s.rock_cx[(size_t)e * R + q], cy = p.s.rock_cy[(size_t)e * R + q];
+            const double rad = p.s.rock_r[(size_t)e * R + q];
+            double sx = 0.0, sy = 0.0;
+            for (int base = 0; base < N; base += 64) {
+                const int i = base + lane;
+                double px = 0.0, py = 0.0;
+                bool col = false;
+                if (i < N) {
+                    const double vx = cx - p.s.x[eN + i], vy = cy - p.s.y[eN + i];
+                    const double d = sqrt(vx * vx + vy * vy);
+                    const double f = 1 - rad / (d + 0.001);
+                    px = vx * f; py = vy * f;
+                    col = !(d > rad);
+                }
+                unsigned long long m = __ballot(col);
+                while (m) {
+                    const int l = __builtin_ctzll(m);
+                    m &= m - 1;
+                    sx += __shfl(px, l);
+                    sy += __shfl(py, l);
+                }
+            }
+            if (lane == 0) {
+                const double wgt = p.s.rock_w[(size_t)e * R + q];
+                rk[2 * q + 0] = cx - sx / wgt;
+                rk[2 * q + 1] = cy - sy / wgt;
+            }
+        }
+        __syncthreads();
+        for (int q = tid; q < R; q += T) {
+            p.s.rock_cx[(size_t)e * R + q] = rk[2 * q + 0];
+            p.s.rock_cy[(size_t)e * R + q] = rk[2 * q + 1];
+        }
+        // pass 2 (:53-58): ants pushed out of the UPDATED rocks, then warp_xy
+        for (int i = tid; i < N; i += T) {
+            const double x = p.s.x[eN + i], y = p.s.y[eN + i];
+            double sx = 0.0, sy = 0.0;
+            for (int q = 0; q < R; ++q) {
+                const double vx = rk[2 * q + 0] - x, vy = rk[2 * q + 1] - y;
+                const double rad = p.s.rock_r[(size_t)e * R + q];
+                const double d = sqrt(vx * vx + vy * vy);
+                const double f = 1 - rad / (d + 0.001);
+                double px = vx * f, py = vy * f;
+                if (d > rad) { px = 0.0; py = 0.0; }
+                sx += px; sy += py;
+            }
+            p.s.x[eN + i] = warp_coord(x + sx, (double)W);
+            p.s.y[eN + i] = warp_coord(y + sy, (double)H);
+        }
+        __syncthreads();
+    }
+
+    // ---- Ants.update, ants.py:123-130: prev := cur; deposit (pheromone.py:36-41)
+    for (int i = tid; i < N; i += T) {
+        const double x = p.s.x[eN + i], y = p.s.y[eN + i];
+        p.s.prev_x[eN + i] = x;
+        p.s.prev_y[eN + i] = y;
+        lww_insert(hkeys, hvals, (uint32_t)p.HT - 1, (uint32_t)((int)x * H + (int)y), (uint32_t)i);
+        p.s.reward_state[eN + i] = (uint8_t)((double)p.s.reward_state[eN + i] * 0.9); // :130
+    }
+    __syncthreads();
+    double gain = 0.0;
+    for (int i = tid; i < N; i += T) {
+        const uint32_t cell = (uint32_t)((int)p.s.x[eN + i] * H + (int)p.s.y[eN + i]);
+        if (lww_winner(hkeys, hvals, (uint32_t)p.HT - 1, cell) == (uint32_t)i) {
+            for (int c = 0; c < C; ++c) {
+                const float a = p.s.activation[(eN + i) * C + c];
+                if (a != 0.0f) {
+                    float v = out[(size_t)cell * C + c] + a;
+                    if (p.has_max_val) v = fminf(v, (float)p.max_val);
+                    out[(size_t)cell * C + c] = v;
+                }
+            }
+        }
+        // ---- Anthill.update (anthill.py:41-46), sparse: after the first full collect the only
+        // non-zero food on the area is what this step's exchange winners wrote there.
+        const int32_t dc = p.s.dirty_cell[eN + i];
+        if (dc >= 0) {
+            gain += (double)food[dc];
+            food[dc] = 0.0f;
+            p.s.dirty_cell[eN + i] = -1;
+        }
+    }
+    // block sum of gain (integer-valued in every reference workload -> order-independent)
+    for (int o = 32; o > 0; o >>= 1) gain += __shfl_down(gain, o);
+    if (lane == 0) red[wave] = gain;
+    __syncthreads();
+    if (tid == 0) {
+        double s = 0.0;
+        for (int w = 0; w < nwaves; ++w) s += red[w];
+        if (s != 0.0) p.s.anthill_food[e] += s;
+        p.s.timestep[e] = ts;
+    }
+}
+
+// Anthill.update over the WHOLE grid (anthill.py:41-46): needed on the first update after a
+// reset (food may lie on the anthill area) and after two steps without an update.
+__global__ void __launch_bounds__(256) k_collect_full(const KP p)
+{
+    __shared__ double red[4];
+    const int e = blockIdx.x, tid = threadIdx.x;
+    const size_t G = (size_t)p.W * p.H;
+    float *food = p.s.food + (size_t)e * G;
+    const uint32_t *area = p.s.area_bits + (size_t)e * p.words;
+    double gain = 0.0;
+    for (size_t g = tid; g < G; g += blockDim.x)
+        if (test_bit(area, (uint32_t)g)) {
+            gain += (double)food[g];
+            food[g] = 0.0f;
+        }
+    for (int o = 32; o > 0; o >>= 1) gain += __shfl_down(gain, o);
+    if ((tid & 63) == 0) red[tid >> 6] = gain;
+    __syncthreads();
+    if (tid == 0) {
+        double s = 0.0;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += red[w];
+        p.s.anthill_food[e] += s;
+    }
+    for (int i = tid; i < p.N; i += blockDim.x) p.s.dirty_cell[(size_t)e * p.N + i] = -1;
+}
+
+// ===================================================================================
+// Pheromone sweep — Walls zeroing (walls.py:30) + Pheromone.update (pheromone.py:43-45)
+// + the whole-grid clip of add_pheromones (pheromone.py:40-41; min is idempotent and the
+// deposit is non-negative, so clipping before the deposit and again at the deposit gives the
+// same grid).
+// ===================================================================================
+// Radius 0 (the shipped DIFFUSE_FACTOR = 0 filter): out = thresh(in * f0), pure streaming,
+// 16 bytes per lane per access.  The product is formed in float64 so that the coefficient
+// (0.999) carries no float32 rounding bias across thousands of steps.
+#define SW0_UNROLL 4
+template <int C>
+__global__ void __launch_bounds__(256)
+k_sweep0(const KP p, const float *__restrict__ in, float *__restrict__ out)
+{
+    // grid = (ceil(per_env / (256*SW0_UNROLL)), E): no per-thread division by the env size
+    const uint32_t per_env = (uint32_t)((size_t)p.W * p.H * C / 4); // float4 per env
+    const size_t e = blockIdx.y;
+    const uint32_t *walls = p.s.walls_bits + e * p.words;
+    const float4 *src = reinterpret_cast<const float4 *>(in) + e * per_env;
+    float4 *dst = reinterpret_cast<float4 *>(out) + e * per_env;
+    const double f0 = p.filter[0], thr = p.threshold;
+    const float mx = (float)p.max_val;
+    const bool clip = p.has_max_val && p.N > 0;
+    const uint32_t v0 = blockIdx.x * (256 * SW0_UNROLL) + threadIdx.x;
+    float4 a[SW0_UNROLL];
+#pragma unroll
+    for (int u = 0; u < SW0_UNROLL; ++u) {
+        const uint32_t v = v0 + u * 256;
+        if (v < per_env) a[u] = src[v];
+    }
+#pragma unroll
+    for (int u = 0; u < SW0_UNROLL; ++u) {
+        const uint32_t v = v0 + u * 256;
+        if (v >= per_env) continue;
+        float r[4] = {a[u].x, a[u].y, a[u].z, a[u].w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t cell = (v * 4 + j) / C;
+            const double o = (double)r[j] * f0;
+            float f = (o < thr) ? 0.0f : (float)o;
+            if (test_bit(walls, cell)) f = 0.0f;
+            if (clip) f = fminf(f, mx);
+            r[j] = f;
+        }
+        dst[v] = make_float4(r[0], r[1], r[2], r[3]);
+    }
+}
+
+// scalar fallback for grids whose float count per env is not a multiple of 4
+template <int C>
+__global__ void __launch_bounds__(256)
+k_sweep0_scalar(const KP p, const float *__restrict__ in, float *__restrict__ out, const size_t n)
+{
+    const size_t per_env = (size_t)p.W * p.H * C;
+    const double f0 = p.filter[0], thr = p.threshold;
+    const bool clip = p.has_max_val && p.N > 0;
+    for (size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x; v < n; v += (size_t)gridDim.x * blockDim.x) {
+        const size_t e = v / per_env;
+        const uint32_t cell = (uint32_t)((v - e * per_env) / C);
+        const double o = (double)in[v] * f0;
+        float f = (o < thr) ? 0.0f : (float)o;
+        if (test_bit(p.s.walls_bits + e * p.words, cell)) f = 0.0f;
+        if (clip) f = fminf(f, (float)p.max_val);
+        out[v] = f;
+    }
+}
+
+// Radius 1..3: LDS-tiled 2-D convolution with zero-fill boundary,
+// scipy.signal.convolve2d(phero, F, 'same', 'fill', 0)  (pheromone.py:44):
+//   out[x,y] = sum_{a,b} F[a,b] * in[x-a+r, y-b+r]   (true convolution: kernel flipped)
+// The wall mask is applied while the tile is staged (walls.py:30 zeroes the INPUT of the
+// convolution, so a wall cell still receives its neighbours' diffusion).
+#define SW_TX 16
+#define SW_TY 64
+template <int C>
+__global__ void __launch_bounds__(256)
+k_sweep_tiled(const KP p, const float *__restrict__ in, float *__restrict__ out)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    float *tile = (float *)smem;
+    const int fr = p.filter_radius, fs = 2 * fr + 1;
+    const int LX = SW_TX + 2 * fr, LY = SW_TY + 2 * fr;
+    const int e = blockIdx.z, x0 = blockIdx.y * SW_TX, y0 = blockIdx.x * SW_TY;
+    const int W = p.W, H = p.H;
+    const size_t G = (size_t)W * H;
+    const float *src = in + (size_t)e * G * C;
+    float *dst = out + (size_t)e * G * C;
+    const uint32_t *walls = p.s.walls_bits + (size_t)e * p.words;
+    for (int t = threadIdx.x; t < LX * LY; t += blockDim.x) {
+        const int lx = t / LY, ly = t - lx * LY;
+        const int gx = x0 + lx - fr, gy = y0 + ly - fr;
+        const bool inside = gx >= 0 && gx < W && gy >= 0 && gy < H;
+        const uint32_t cell = inside ? (uint32_t)(gx * H + gy) : 0u;
+        const bool live = inside && !test_bit(walls, cell);
+#pragma unroll
+        for (int c = 0; c < C; ++c) tile[(size_t)t * C + c] = live ? src[(size_t)cell * C + c] : 0.0f;
+    }
+    __syncthreads();
+    const bool clip = p.has_max_val && p.N > 0;
+    for (int t = threadIdx.x; t < SW_TX * SW_TY; t += blockDim.x) {
+        const int lx = t / SW_TY, ly = t - lx * SW_TY;
+        const int gx = x0 + lx, gy = y0 + ly;
+        if (gx >= W || gy >= H) continue;
+        double acc[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) acc[c] = 0.0;
+        for (int a = 0; a < fs; ++a)
+            for (int b = 0; b < fs; ++b) {
+                const double f = p.filter[a * fs + b];
+                const float *tp = tile + ((size_t)(lx - a + 2 * fr) * LY + (ly - b + 2 * fr)) * C;
+#pragma unroll
+                for (int c = 0; c < C; ++c) acc[c] += f * (double)tp[c];
+            }
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            float f = (acc[c] < p.threshold) ? 0.0f : (float)acc[c];
+            if (clip) f = fminf(f, (float)p.max_val);
+            dst[((size_t)gx * H + gy) * C + c] = f;
+        }
+    }
+}
+
+// ===================================================================================
+// reset / state I/O (not on the hot path)
+// ===================================================================================
+__global__ void k_reset_ants(const KP p, const double *__restrict__ xyt, const double *__restrict__ seed)
+{
+    const size_t n = (size_t)p.E * p.N;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t e = i / p.N;
+        const double x = warp_coord(xyt[3 * i + 0], (double)p.W); // ants.py:27-30
+        const double y = warp_coord(xyt[3 * i + 1], (double)p.H);
+        p.s.x[i] = x; p.s.y[i] = y; p.s.theta[i] = xyt[3 * i + 2];
+        p.s.prev_x[i] = x; p.s.prev_y[i] = y;
+        p.s.holding[i] = 0.0f; p.s.prev_holding[i] = 0.0f;
+        p.s.mandibles[i] = 0; p.s.reward_state[i] = 0;
+        p.s.seed[i] = (float)seed[i];
+        p.s.dirty_cell[i] = -1;
+        for (int c = 0; c < p.C; ++c) p.s.activation[i * p.C + c] = 0.0f;
+        const double dx = x - (double)p.s.anthill_xyr[3 * e + 0], dy = y - (double)p.s.anthill_xyr[3 * e + 1];
+        p.s.prev_dist[i] = sqrt(dx * dx + dy * dy); // reward_custom.py:77
+    }
+}
+
+__global__ void k_reset_env(const KP p, const int32_t *__restrict__ xyr, const double *__restrict__ rocks)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= p.E) return;
+    for (int j = 0; j < 3; ++j) p.s.anthill_xyr[3 * e + j] = xyr[3 * e + j];
+    p.s.anthill_food[e] = 0.0;
+    p.s.timestep[e] = 1; // environment.py:27
+    p.s.reward_primed[e] = 0;
+    for (int q = 0; q < p.R; ++q) {
+        p.s.rock_cx[(size_t)e * p.R + q] = rocks[((size_t)e * p.R + q) * 4 + 0];
+        p.s.rock_cy[(size_t)e * p.R + q] = rocks[((size_t)e * p.R + q) * 4 + 1];
+        p.s.rock_r[(size_t)e * p.R + q] = rocks[((size_t)e * p.R + q) * 4 + 2];
+        p.s.rock_w[(size_t)e * p.R + q] = rocks[((size_t)e * p.R + q) * 4 + 3];
+    }
+}
+
+// bit-pack walls, rasterise the anthill disc (anthill.py:28-33), clear the explored map
+__global__ void k_reset_bits(const KP p, const uint8_t *__restrict__ walls, const int32_t *__restrict__ xyr)
+{
+    const size_t n = (size_t)p.E * p.words;
+    const size_t G = (size_t)p.W * p.H;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t e = i / p.words, w = i - e * p.words;
+        const long ax = xyr[3 * e + 0], ay = xyr[3 * e + 1], ar = xyr[3 * e + 2];
+        uint32_t wb = 0, ab = 0;
+        for (int b = 0; b < 32; ++b) {
+            const size_t cell = w * 32 + b;
+            if (cell >= G) break;
+            if (walls[e * G + cell]) wb |= 1u << b;
+            const long x = (long)(cell / p.H), y = (long)(cell % p.H);
+            // integer ax, ay, r: sqrt(d2) <= r  <=>  d2 <= r*r  (and r < 0 -> empty)
+            if (ar >= 0 && (ax - x) * (ax - x) + (ay - y) * (ay - y) <= ar * ar) ab |= 1u << b;
+        }
+        p.s.walls_bits[i] = wb;
+        p.s.area_bits[i] = ab;
+        p.s.explored_bits[i] = 0u;
+    }
+}
+
+__global__ void k_reset_grids(const KP p, const float *__restrict__ food, const float *__restrict__ phero)
+{
+    const size_t G = (size_t)p.W * p.H, n = (size_t)p.E * G;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t e = i / G, g = i - e * G;
+        p.s.food[i] = food[i];
+        for (int c = 0; c < p.C; ++c) {
+            const float v = phero ? phero[(e * p.C + c) * G + g] : 0.0f;
+            p.s.phero[0][i * p.C + c] = v;
+            p.s.phero[1][i * p.C + c] = v;
+        }
+    }
+}
+
+__global__ void k_set_activation(const KP p, const float *__restrict__ act)
+{
+    const size_t n = (size_t)p.E * p.N * p.C;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        p.s.activation[i] = act[i];
+}
+
+__global__ void k_read_state(const KP p, const int which, const int cur, void *__restrict__ dstv)
+{
+    const size_t EN = (size_t)p.E * p.N, G = (size_t)p.W * p.H, EG = (size_t)p.E * G;
+    const size_t stride = (size_t)gridDim.x * blockDim.x, t0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    switch (which) {
+    case ANTSRL_S_ANTS_XYT:
+        for (size_t i = t0; i < EN; i += stride) {
+            double *d = (double *)dstv + 3 * i;
+            d[0] = p.s.x[i]; d[1] = p.s.y[i]; d[2] = p.s.theta[i];
+        }
+        break;
+    case ANTSRL_S_PREV_XY:
+        for (size_t i = t0; i < EN; i += stride) {
+            ((double *)dstv)[2 * i] = p.s.prev_x[i];
+            ((double *)dstv)[2 * i + 1] = p.s.prev_y[i];
+        }
+        break;
+    case ANTSRL_S_HOLDING: for (size_t i = t0; i < EN; i += stride) ((float *)dstv)[i] = p.s.holding[i]; break;
+    case ANTSRL_S_SEED: for (size_t i = t0; i < EN; i += stride) ((float *)dstv)[i] = p.s.seed[i]; break;
+    case ANTSRL_S_MANDIBLES: for (size_t i = t0; i < EN; i += stride) ((uint8_t *)dstv)[i] = p.s.mandibles[i]; break;
+    case ANTSRL_S_REWARD_STATE: for (size_t i = t0; i < EN; i += stride) ((uint8_t *)dstv)[i] = p.s.reward_state[i]; break;
+    case ANTSRL_S_ACTIVATION:
+        for (size_t i = t0; i < EN * p.C; i += stride) ((float *)dstv)[i] = p.s.activation[i];
+        break;
+    case ANTSRL_S_PHERO: // interleaved [E][G][C] -> canonical [E][C][G]
+        for (size_t i = t0; i < EG * p.C; i += stride) {
+            const size_t e = i / (G * p.C), rem = i - e * G * p.C, c = rem / G, g = rem - c * G;
+            ((float *)dstv)[i] = p.s.phero[cur][(e * G + g) * p.C + c];
+        }
+        break;
+    case ANTSRL_S_FOOD: for (size_t i = t0; i < EG; i += stride) ((float *)dstv)[i] = p.s.food[i]; break;
+    case ANTSRL_S_EXPLORED:
+    case ANTSRL_S_WALLS:
+    case ANTSRL_S_ANTHILL_AREA: {
+        const uint32_t *bits = which == ANTSRL_S_EXPLORED ? p.s.explored_bits
+                               : which == ANTSRL_S_WALLS  ? p.s.walls_bits : p.s.area_bits;
+        for (size_t i = t0; i < EG; i += stride) {
+            const size_t e = i / G, g = i - e * G;
+            ((uint8_t *)dstv)[i] = (uint8_t)test_bit(bits + e * p.words, (uint32_t)g);
+        }
+    } break;
+    case ANTSRL_S_ANTHILL_FOOD: for (size_t i = t0; i < (size_t)p.E; i += stride) ((double *)dstv)[i] = p.s.anthill_food[i]; break;
+    case ANTSRL_S_TIMESTEP: for (size_t i = t0; i < (size_t)p.E; i += stride) ((int32_t *)dstv)[i] = p.s.timestep[i]; break;
+    case ANTSRL_S_ROCK_CENTERS:
+        for (size_t i = t0; i < (size_t)p.E * p.R; i += stride) {
+            ((double *)dstv)[2 * i] = p.s.rock_cx[i];
+            ((double *)dstv)[2 * i + 1] = p.s.rock_cy[i];
+        }
+        break;
+    default: break;
+    }
+}
+
+// ===================================================================================
+// host-side launchers (called from antsrl_capi.hip)
+// ===================================================================================
+static inline int pick_act_threads(int N) { return N <= 256 ? 256 : 512; }
+
+struct ActPlan {
+    int threads;
+    bool static_lds;
+    size_t lds;
+};
+
+// LDS budget: 160 KiB per CU.  Prefer two resident workgroups per CU (<= 80 KiB each) with
+// the walls/anthill bitmaps staged too; otherwise one 1024-thread workgroup per CU.
+static ActPlan plan_act(const KP &p)
+{
+    const size_t cap = 160 * 1024;
+    const int t0 = pick_act_threads(p.N);
+    // {threads, walls/anthill bitmaps in LDS, LDS limit}: prefer two resident workgroups per
+    // CU (<= 80 KiB each), then one 1024-thread workgroup, then fewer waves (smaller staging).
+    const struct { int threads; bool st; size_t limit; } cand[] = {
+        {t0, true, cap / 2}, {t0, false, cap / 2}, {1024, true, cap}, {1024, false, cap},
+        {512, false, cap},   {256, false, cap},
+    };
+    ActPlan pl{};
+    for (const auto &c : cand) {
+        pl.threads = c.threads;
+        pl.static_lds = c.st;
+        pl.lds = act_lds_bytes(p.N, p.PP, p.words, p.HT, p.K, c.threads / 64, c.st, nullptr, nullptr);
+        if (pl.lds <= c.limit) return pl;
+    }
+    return pl; // caller checks pl.lds <= cap
+}
+
+static size_t update_lds_bytes(const KP &p, int threads)
+{
+    return align_up(8 * (size_t)p.HT, 16) + 16 * (size_t)(p.R > 0 ? p.R : 1) + 8 * (size_t)(threads / 64) +
+           4 * (size_t)(threads / 64) + 16;
+}
+
+template <int C>
+static hipError_t launch_act_c(const KP &p, const int8_t *rot, const int8_t *ph, int cur, float *obs,
+                               float *agent_state, float *reward, uint8_t *done, int flags, hipStream_t st)
+{
+    const ActPlan pl = plan_act(p);
+    if (pl.lds > 160 * 1024) return hipErrorInvalidValue;
+    hipError_t err;
+    if (pl.static_lds) {
+        err = hipFuncSetAttribute((const void *)k_act<C, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds);
+        if (err != hipSuccess) return err;
+        hipLaunchKernelGGL((k_act<C, true>), dim3(p.E), dim3(pl.threads), pl.lds, st, p, rot, ph, cur, obs,
+                           agent_state, reward, done, flags);
+    } else {
+        err = hipFuncSetAttribute((const void *)k_act<C, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds);
+        if (err != hipSuccess) return err;
+        hipLaunchKernelGGL((k_act<C, false>), dim3(p.E), dim3(pl.threads), pl.lds, st, p, rot, ph, cur, obs,
+                           agent_state, reward, done, flags);
+    }
+    return hipGetLastError();
+}
+
+hipError_t antsrl_launch_act(const KP &p, const int8_t *rot, const int8_t *ph, int cur, float *obs,
+                             float *agent_state, float *reward, uint8_t *done, int flags, hipStream_t st)
+{
+    switch (p.C) {
+    case 1: return launch_act_c<1>(p, rot, ph, cur, obs, agent_state, reward, done, flags, st);
+    case 2: return launch_act_c<2>(p, rot, ph, cur, obs, agent_state, reward, done, flags, st);
+    case 3: return launch_act_c<3>(p, rot, ph, cur, obs, agent_state, reward, done, flags, st);
+    case 4: return launch_act_c<4>(p, rot, ph, cur, obs, agent_state, reward, done, flags, st);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+bool antsrl_act_fits(const KP &p) { return plan_act(p).lds <= 160 * 1024; }
+
+template <int C>
+static hipError_t launch_sweep_c(const KP &p, int cur, hipStream_t st)
+{
+    const float *in = p.s.phero[cur];
+    float *out = p.s.phero[cur ^ 1];
+    const size_t n = (size_t)p.E * p.W * p.H * C;
+    if (p.filter_radius == 0) {
+        if (((size_t)p.W * p.H * C) % 4 == 0) {
+            const size_t per_env4 = (size_t)p.W * p.H * C / 4;
+            const unsigned bx = (unsigned)((per_env4 + 256 * SW0_UNROLL - 1) / (256 * SW0_UNROLL));
+            hipLaunchKernelGGL((k_sweep0<C>), dim3(bx, (unsigned)p.E), dim3(256), 0, st, p, in, out);
+        } else {
+            size_t blocks = (n + 255) / 256;
+            if (blocks > 256 * 64) blocks = 256 * 64;
+            hipLaunchKernelGGL((k_sweep0_scalar<C>), dim3((unsigned)blocks), dim3(256), 0, st, p, in, out, n);
+        }
+    } else {
+        const int fr = p.filter_radius;
+        const size_t lds = (size_t)(SW_TX + 2 * fr) * (SW_TY + 2 * fr) * C * sizeof(float);
+        dim3 grid((p.H + SW_TY - 1) / SW_TY, (p.W + SW_TX - 1) / SW_TX, p.E);
+        hipLaunchKernelGGL((k_sweep_tiled<C>), grid, dim3(256), lds, st, p, in, out);
+    }
+    return hipGetLastError();
+}
+
+hipError_t antsrl_launch_sweep(const KP &p, int cur, hipStream_t st)
+{
+    switch (p.C) {
+    case 1: return launch_sweep_c<1>(p, cur, st);
+    case 2: return launch_sweep_c<2>(p, cur, st);
+    case 3: return launch_sweep_c<3>(p, cur, st);
+    case 4: return launch_sweep_c<4>(p, cur, st);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t antsrl_launch_update(const KP &p, const double *jitter, int out_buf, hipStream_t st)
+{
+    const int threads = pick_act_threads(p.N);
+    const size_t lds = update_lds_bytes(p, threads);
+    switch (p.C) {
+    case 1: hipLaunchKernelGGL((k_update<1>), dim3(p.E), dim3(threads), lds, st, p, jitter, out_buf); break;
+    case 2: hipLaunchKernelGGL((k_update<2>), dim3(p.E), dim3(threads), lds, st, p, jitter, out_buf); break;
+    case 3: hipLaunchKernelGGL((k_update<3>), dim3(p.E), dim3(threads), lds, st, p, jitter, out_buf); break;
+    case 4: hipLaunchKernelGGL((k_update<4>), dim3(p.E), dim3(threads), lds, st, p, jitter, out_buf); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t antsrl_launch_collect_full(const KP &p, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_collect_full, dim3(p.E), dim3(256), 0, st, p);
+    return hipGetLastError();
+}
+
+static inline unsigned grid_for(size_t n)
+{
+    size_t b = (n + 255) / 256;
+    if (b > 65536) b = 65536;
+    if (b < 1) b = 1;
+    return (unsigned)b;
+}
+
+hipError_t antsrl_launch_reset(const KP &p, const AntsInit *in, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_reset_env, dim3((p.E + 255) / 256), dim3(256), 0, st, p, in->anthill_xyr, in->rocks);
+    hipLaunchKernelGGL(k_reset_ants, dim3(grid_for((size_t)p.E * p.N)), dim3(256), 0, st, p, in->ants_xyt, in->seed);
+    hipLaunchKernelGGL(k_reset_bits, dim3(grid_for((size_t)p.E * p.words)), dim3(256), 0, st, p, in->walls,
+                       in->anthill_xyr);
+    hipLaunchKernelGGL(k_reset_grids, dim3(grid_for((size_t)p.E * p.W * p.H)), dim3(256), 0, st, p, in->food,
+                       in->phero);
+    return hipGetLastError();
+}
+
+hipError_t antsrl_launch_set_activation(const KP &p, const float *act, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_set_activation, dim3(grid_for((size_t)p.E * p.N * p.C)), dim3(256), 0, st, p, act);
+    return hipGetLastError();
+}
+
+hipError_t antsrl_launch_read_state(const KP &p, int which, int cur, void *dst, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_read_state, dim3(grid_for((size_t)p.E * p.W * p.H)), dim3(256), 0, st, p, which, cur, dst);
+    return hipGetLastError();
+}

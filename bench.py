@@ -1,0 +1,245 @@
+#!/usr/bin/env python3
+"""bench.py — ant-steps/s of the AntsRL environment step loop on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c3|c2|c4]
+
+One "step" = RLApi.step + Environment.update (main.py:98 + main.py:131 of the reference) over one
+batch of E environments, through the C-ABI (antsrl_step_update).  Default workload is BASELINE.json
+configs[2] — the configuration the metric is quoted on: 1024 envs x 512 ants, 256x256 grid, 2
+pheromone channels, walls + food + 8 circle obstacles, ExplorationReward, uniform random policy
+(actions pre-generated on the device, resident in HBM before the timed region).
+
+For N > 1 the driver launches this file under torch.distributed.run, one rank per GPU.  The
+environments are independent, so every rank steps its own E envs (weak scaling, no data-path
+collective) and the only exchange is the RCCL all-gather of reward/done each step.
+
+Prints ONE JSON line on rank 0 (see DESIGN.md for the roofline byte accounting).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CONFIGS = {
+    # name: (E per GPU, N, W, H, R, radius-3 filter?)
+    "c2": dict(E=256, N=256, W=256, H=256, R=0, radius3=False,
+               desc="BASELINE configs[1]: 256 envs x 256 ants, 256x256, 2 pheromone channels"),
+    "c3": dict(E=1024, N=512, W=256, H=256, R=8, radius3=False,
+               desc="BASELINE configs[2]: 1024 envs x 512 ants, 256x256, circle_obstacles+walls+food"),
+    "c4": dict(E=1024, N=1024, W=512, H=512, R=0, radius3=True,
+               desc="BASELINE configs[3] per-GPU shard: 1024 envs x 1024 ants, 512x512, diffuse radius 3"),
+}
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def algorithmic_bytes(N, W, H, Cn, K, P=49):
+    """SURVEY.md §8(d) per env-step figure, split by the kernel that moves each term."""
+    sweep = 2 * Cn * W * H * 4 + W * H                 # pheromone read+write sweep, wall mask
+    act = N * P * K * 4 + N * 60 + N * 12 + N * 8      # obs write, ant state r+w, agent_state+reward, food RMW
+    update = N * Cn * 8                                # deposit RMW
+    return dict(sweep=sweep, act=act, update=update, total=sweep + act + update)
+
+
+class HipEvents:
+    """Raw hipEvent_t handles (the ABI hook records them on the launch stream)."""
+
+    def __init__(self, n):
+        from antsrl_amd._lib import hip_runtime
+        self.hip = hip_runtime()  # the runtime torch already loaded, not a second copy
+        self.ev = []
+        for _ in range(n):
+            e = C.c_void_p()
+            rc = self.hip.hipEventCreate(C.byref(e))
+            assert rc == 0, "hipEventCreate failed: %d" % rc
+            self.ev.append(e)
+
+    def elapsed_ms(self, a, b):
+        ms = C.c_float()
+        rc = self.hip.hipEventElapsedTime(C.byref(ms), self.ev[a], self.ev[b])
+        assert rc == 0, "hipEventElapsedTime failed: %d" % rc
+        return ms.value
+
+    def destroy(self):
+        for e in self.ev:
+            self.hip.hipEventDestroy(e)
+
+
+def usable_cores():
+    """CPU share this process may really use: affinity mask capped by the cgroup quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except Exception:
+        pass
+    return max(1, n)
+
+
+def cpu_baseline(cfg_kw, make_cfg, synth_init, random_actions, budget_s=15.0):
+    """The CPU oracle (a plain-C port of the reference algorithm, pinned to the reference by the
+    golden fixtures) timed on this box's host cores on a bounded sample of the same workload."""
+    from oracle.oracle import Oracle, max_threads
+    cores = min(max_threads(), usable_cores())
+    E = max(cores, 16)
+    cfg = make_cfg(E, cfg_kw["N"], cfg_kw["W"], cfg_kw["H"], **cfg_kw["extra"])
+    init = synth_init(cfg, seed=4321)
+    orc = Oracle(cfg, init, n_threads=cores)
+    rot, ph = random_actions(cfg, 4, seed=7)
+
+    def one(t):
+        orc.step(rot[t % 4], ph[t % 4])
+        orc.update(None)
+
+    one(0)
+    t0 = time.perf_counter()
+    one(1)
+    one(2)
+    per = (time.perf_counter() - t0) / 2
+    steps = int(max(3, min(2000, budget_s / max(per, 1e-6))))
+    t0 = time.perf_counter()
+    for t in range(steps):
+        one(t)
+    dt = time.perf_counter() - t0
+    return dict(value=E * cfg.n_ants * steps / dt, unit="ant-steps/s", cores=cores, kind="port",
+                sample="%d envs x %d ants, %dx%d grid, %d full steps (RLApi.step + Environment.update) "
+                       "of the same workload; oracle/antsrl_oracle.c, OpenMP over envs, %.1f s"
+                       % (E, cfg.n_ants, cfg.w, cfg.h, steps, dt))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
+    ap.add_argument("--envs", type=int, default=0, help="override envs per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world == 1:
+        sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)  # backend "nccl" is RCCL on ROCm
+
+    from antsrl_amd import config as cm
+    from antsrl_amd.batched import BatchedAntsEnv
+    from antsrl_amd.synth import random_actions, synth_init
+
+    W_ = CONFIGS[args.config]
+    E = args.envs or W_["E"]
+    extra = dict(n_rocks=W_["R"], deposit_strength=256.0, max_time=1 << 30)
+    if W_["radius3"]:
+        ax = np.arange(-3, 4)
+        g = np.exp(-(ax[:, None] ** 2 + ax[None, :] ** 2) / 4.5)
+        extra["filt"] = g / g.sum() * (1 - 0.001)
+    cfg = cm.make_cfg(E, W_["N"], W_["W"], W_["H"], **extra)
+    env = BatchedAntsEnv(cfg, dev)
+    env.reset(synth_init(cfg, seed=1234, env_offset=rank * E))
+    RING = 8
+    g = torch.Generator(device=dev)
+    g.manual_seed(99 + rank)
+    rot = torch.randint(-1, 2, (RING, E, cfg.n_ants), generator=g, device=dev, dtype=torch.int8)
+    ph = torch.randint(0, 3, (RING, E, cfg.n_ants), generator=g, device=dev, dtype=torch.int8)
+    if world > 1:
+        rew_all = torch.empty((world * E, cfg.n_ants), dtype=torch.float32, device=dev)
+        done_all = torch.empty((world * E,), dtype=torch.uint8, device=dev)
+
+    def one_step(t):
+        env.step_update(rot[t % RING], ph[t % RING], None)
+        if world > 1:  # the path's only exchange: reward/done all-gather
+            dist.all_gather_into_tensor(rew_all, env.reward)
+            dist.all_gather_into_tensor(done_all, env.done)
+
+    for t in range(args.warmup):
+        one_step(t)
+
+    K = args.steps
+    timing = not args.no_kernel_timing
+    evs = HipEvents(4 * K) if timing else None
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    barrier()
+    t0 = time.perf_counter()
+    for t in range(K):
+        if timing:
+            env.set_timing_events([evs.ev[4 * t + i].value for i in range(4)])
+        one_step(args.warmup + t)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    out = None
+    if rank == 0:
+        ab = algorithmic_bytes(cfg.n_ants, cfg.w, cfg.h, cfg.n_phero, cfg.n_channels)
+        kern = {}
+        if timing:
+            ms = np.array([[evs.elapsed_ms(4 * t + i, 4 * t + i + 1) for i in range(3)] for t in range(K)])
+            kern = dict(sweep=float(ms[:, 0].mean()), act=float(ms[:, 1].mean()), update=float(ms[:, 2].mean()))
+            dom = max(kern, key=kern.get)
+            names = dict(sweep="k_sweep0" if cfg.filter_radius == 0 else "k_sweep_tiled", act="k_act", update="k_update")
+            achieved = ab[dom] * E / (kern[dom] * 1e-3) / 1e9
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.config)
+            if os.path.exists(tpath):  # PMC-derived HBM bytes per launch, from a separate rocprofv3 --pmc run
+                traffic = json.load(open(tpath)).get(names[dom])
+            roofline = dict(bound="hbm", kernel=names[dom], achieved=round(achieved, 1), peak=HBM_PEAK_GBS,
+                            unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic,
+                            algorithmic_bytes_per_launch=ab[dom] * E,
+                            kernel_ms={names[k]: round(v, 4) for k, v in kern.items()},
+                            step_algorithmic_gbs=round(ab["total"] * E / (elapsed / K) / 1e9, 1))
+        else:
+            roofline = dict(bound="hbm", achieved=None, peak=HBM_PEAK_GBS, unit="GB/s", frac=None, traffic=None)
+        value = world * E * cfg.n_ants * K / elapsed
+        out = {
+            "metric": "ant-steps/sec (ants x envs x steps/s), 256^2 grid" if cfg.w == 256 else "ant-steps/sec (ants x envs x steps/s)",
+            "value": value, "unit": "ant-steps/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
+            "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64 ant kinematics / f32 grids", "data": "synthetic",
+            "config": {"workload": W_["desc"], "envs_per_gpu": E, "ants": cfg.n_ants, "grid": [cfg.w, cfg.h],
+                       "pheromone_channels": cfg.n_phero, "rocks": cfg.n_rocks, "obs_channels": cfg.n_channels,
+                       "filter_radius": cfg.filter_radius, "reward": "ExplorationReward",
+                       "policy": "uniform random, pre-generated on device",
+                       "parallelism": "env-sharded x%d, reward/done all-gather" % world},
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(dict(N=cfg.n_ants, W=cfg.w, H=cfg.h, extra=extra),
+                                               cm.make_cfg, synth_init, random_actions)
+    if evs:
+        evs.destroy()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -158,6 +158,9 @@ enum {
 /* Library / ABI version (ANTSRL_ABI_VERSION of the build). */
 int antsrl_abi_version(void);
 
+/* sizeof(AntsCfg) as the library was compiled: lets a binding verify its struct mirror. */
+size_t antsrl_cfg_size(void);
+
 /* Message for the last error returned on this thread ("" if none). */
 const char *antsrl_last_error(void);
 
@@ -207,6 +210,13 @@ int antsrl_update(AntsHandle *h, const double *wall_jitter, void *stream);
 int antsrl_step_update(AntsHandle *h, const int8_t *rotation, const int8_t *phero,
                        const double *wall_jitter, float *obs, float *agent_state, float *reward,
                        uint8_t *done, void *stream);
+
+/* Measurement hook (no reference counterpart; the reference only keeps a wall-clock EMA,
+ * main.py:93,132-136).  events = 4 caller-created hipEvent_t, or NULL to disable.  While set,
+ * the NEXT antsrl_step_update records them on its stream: [0] before the pheromone sweep,
+ * [1] after it, [2] after the act/observe kernel, [3] after the update kernel; the hook then
+ * clears itself. */
+int antsrl_set_timing_events(AntsHandle *h, void *const *events);
 
 /* Ants.activate_all_pheromones (environment/ants.py:86-87).  act: float [E][N][C].
  * new_deposit_strength > 0 also changes AntsCfg.deposit_strength (the dtype switch

@@ -1,0 +1,99 @@
+"""CPU-side checks of the C-ABI library: it loads without a GPU, exports every symbol
+include/antsrl.h declares, its AntsCfg layout matches the ctypes mirror, and its host-only
+entry points validate their arguments.  No kernel is launched here."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from antsrl_amd import _lib
+from antsrl_amd import build as buildmod
+from antsrl_amd.config import AntsCfg, make_cfg
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    buildmod.build_hip()
+    return _lib.load()
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "antsrl.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(antsrl_[a-z_]+)\s*\(", text)))
+
+
+def test_header_symbols_are_exported(lib):
+    names = declared_symbols()
+    assert len(names) >= 13
+    for n in names:
+        assert hasattr(lib, n), "libantsrl_hip.so does not export %s" % n
+    assert sorted(_lib.EXPORTS) == names
+
+
+def test_layout_and_version(lib):
+    assert lib.antsrl_abi_version() == 1
+    assert lib.antsrl_cfg_size() == C.sizeof(AntsCfg)
+
+
+def test_workspace_bytes_and_validation(lib):
+    cfg = make_cfg(1024, 512, 256, 256, n_rocks=8)
+    n = C.c_size_t()
+    assert lib.antsrl_workspace_bytes(C.byref(cfg), C.byref(n)) == 0
+    # 2 pheromone buffers + food + bitmaps + ant SoA, ~1.3 GiB
+    assert 1.2 * 2 ** 30 < n.value < 1.5 * 2 ** 30
+    bad = cfg.copy()
+    bad.n_phero = 9
+    assert lib.antsrl_workspace_bytes(C.byref(bad), C.byref(n)) == -1
+    assert b"n_phero" in lib.antsrl_last_error()
+    bad = cfg.copy()
+    bad.abi_version = 7
+    assert lib.antsrl_workspace_bytes(C.byref(bad), C.byref(n)) == -1
+
+
+def test_create_rejects_bad_workspace(lib):
+    cfg = make_cfg(2, 8, 16, 16)
+    h = C.c_void_p()
+    assert lib.antsrl_create(C.byref(cfg), None, 0, C.byref(h)) == -1
+    # fake (never dereferenced on the host) aligned pointer, but too small
+    assert lib.antsrl_create(C.byref(cfg), C.c_void_p(4096), 16, C.byref(h)) == -2
+    assert b"too small" in lib.antsrl_last_error()
+    n = C.c_size_t()
+    lib.antsrl_workspace_bytes(C.byref(cfg), C.byref(n))
+    assert lib.antsrl_create(C.byref(cfg), C.c_void_p(4096 + 8), n.value, C.byref(h)) == -1  # misaligned
+    assert lib.antsrl_create(C.byref(cfg), C.c_void_p(4096), n.value, C.byref(h)) == 0
+    # not reset yet: every state-touching call refuses, nothing is launched
+    assert lib.antsrl_update(h, None, None) == -1
+    assert b"antsrl_reset" in lib.antsrl_last_error()
+    lib.antsrl_destroy(h)
+
+
+def test_lds_budget_is_checked(lib):
+    cfg = make_cfg(1, 64, 2048, 2048)  # 3 x 512 KiB bitmaps cannot live in 160 KiB of LDS
+    n = C.c_size_t()
+    lib.antsrl_workspace_bytes(C.byref(cfg), C.byref(n))
+    h = C.c_void_p()
+    assert lib.antsrl_create(C.byref(cfg), C.c_void_p(4096), n.value, C.byref(h)) == -4
+
+
+def test_product_never_imports_oracle():
+    """The product path must not route through the CPU oracle (or any CPU fallback)."""
+    pkg = os.path.join(ROOT, "antsrl_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle", src, flags=re.M), f
+                assert "liboracle" not in src, f
+
+
+def test_batched_env_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.device_count() > 0:
+        pytest.skip("GPU present")
+    from antsrl_amd.batched import BatchedAntsEnv
+    with pytest.raises(_lib.AntsrlError):
+        BatchedAntsEnv(make_cfg(1, 4, 16, 16))

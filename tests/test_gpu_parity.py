@@ -1,0 +1,282 @@
+"""GPU parity tests: the HIP path (through the C-ABI) against the reference's golden vectors
+and against the CPU oracle on identical inputs.
+
+Bar (BASELINE.json north_star): ant cell indices, holding / pickup counts, mandibles, food,
+anthill.food, explored map, integer perception channels, reward and done BIT-EXACT; ant
+coordinates within 1e-9 (device sin/cos may differ from glibc in the last ulp); pheromone grid
+and pheromone perception channels within 1e-5 (fp32 grid vs float64 reference, comparator
+`helpers.phero_close`).
+"""
+import numpy as np
+import pytest
+
+from helpers import OP_OBSERVE, OP_STEP, OP_UPDATE, fixture_names, load_fixture, phero_close
+
+pytestmark = pytest.mark.gpu
+
+XY_ATOL = 1e-9
+
+
+@pytest.fixture(scope="module")
+def torch_mod():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return torch
+
+
+def _cpu(t):
+    return t.detach().cpu().numpy()
+
+
+def check_obs(cfg, got, want, ctx):
+    """got f32 [N,P,P,K], want f64 [N,P,P,K]."""
+    from antsrl_amd import config as cm
+    for k in range(cfg.n_channels):
+        g, w = got[..., k].astype(np.float64), want[..., k]
+        if cfg.channel_kind[k] == cm.CH_PHERO:
+            # masked cells are exactly -1 on both sides
+            np.testing.assert_array_equal(g == -1.0, w == -1.0, err_msg=ctx + " mask ch%d" % k)
+            ok = np.abs(g - w) <= 1e-5 + 1e-5 * np.abs(w)
+            # a cell at the 0.01 cut (pheromone.py:45) may read 0 on one side
+            thr = 0.01 / cfg.phero_max_val
+            ok |= (np.minimum(g, w) == 0) & (np.abs(np.maximum(g, w) - thr) <= 1e-4 * thr)
+            assert ok.all(), "%s phero channel %d: %d cells off, max |d|=%g" % (
+                ctx, k, (~ok).sum(), np.abs(g - w)[~ok].max())
+        else:
+            np.testing.assert_array_equal(g, w, err_msg=ctx + " channel %d" % k)
+
+
+def check_state(env, cfg, F, t, meta, ctx, envs, with_phero):
+    from antsrl_amd import config as cm
+    xyt = _cpu(env.read_state(cm.S_ANTS_XYT))
+    prev = _cpu(env.read_state(cm.S_PREV_XY))
+    hold = _cpu(env.read_state(cm.S_HOLDING))
+    mand = _cpu(env.read_state(cm.S_MANDIBLES))
+    act = _cpu(env.read_state(cm.S_ACTIVATION))
+    rs = _cpu(env.read_state(cm.S_REWARD_STATE))
+    food = _cpu(env.read_state(cm.S_FOOD))
+    ts = _cpu(env.read_state(cm.S_TIMESTEP))
+    af = _cpu(env.read_state(cm.S_ANTHILL_FOOD))
+    expl = _cpu(env.read_state(cm.S_EXPLORED))
+    rc = _cpu(env.read_state(cm.S_ROCK_CENTERS)) if cfg.n_rocks else None
+    ph = _cpu(env.read_state(cm.S_PHERO)) if with_phero else None
+    for e in envs:
+        np.testing.assert_allclose(xyt[e], F["ants"][t], rtol=0, atol=XY_ATOL, err_msg=ctx)
+        np.testing.assert_array_equal(np.floor(xyt[e][:, :2]), np.floor(F["ants"][t][:, :2]), err_msg=ctx + " cells")
+        np.testing.assert_allclose(prev[e], F["prev"][t], rtol=0, atol=XY_ATOL, err_msg=ctx)
+        np.testing.assert_array_equal(hold[e], F["holding"][t], err_msg=ctx + " holding")
+        np.testing.assert_array_equal(mand[e], F["mandibles"][t], err_msg=ctx + " mandibles")
+        np.testing.assert_array_equal(act[e], F["activation"][t], err_msg=ctx + " activation")
+        np.testing.assert_array_equal(rs[e], F["reward_state"][t], err_msg=ctx + " reward_state")
+        np.testing.assert_array_equal(food[e], F["food"][t], err_msg=ctx + " food")
+        assert ts[e] == F["timestep"][t], ctx
+        assert af[e] == F["anthill_food"][t], ctx + " anthill_food"
+        if meta["reward"] in ("exploration", "all"):
+            np.testing.assert_array_equal(expl[e], F["explored"][t], err_msg=ctx + " explored")
+        if cfg.n_rocks:
+            np.testing.assert_allclose(rc[e], F["rock_centers"][t], rtol=0, atol=XY_ATOL, err_msg=ctx)
+        if with_phero:
+            ok = phero_close(ph[e], F["phero"][t], threshold=cfg.phero_threshold)
+            assert ok.all(), "%s pheromone: %d cells off, max |d|=%g" % (
+                ctx, (~ok).sum(), np.abs(ph[e] - F["phero"][t])[~ok].max())
+
+
+@pytest.mark.parametrize("name", fixture_names())
+def test_hip_matches_reference_golden(torch_mod, name):
+    """Replay every recorded reference run through antsrl_step / antsrl_update / antsrl_observe."""
+    from antsrl_amd.batched import BatchedAntsEnv
+    n_envs = 3
+    cfg, init, F, meta = load_fixture(name, n_envs)
+    env = BatchedAntsEnv(cfg)
+    env.reset(init)
+    from antsrl_amd import config as cm
+    np.testing.assert_array_equal(_cpu(env.read_state(cm.S_ANTHILL_AREA))[1], F["init_anthill_area"].astype(np.uint8))
+    if meta["deposit_strength"] != 1.0:
+        env.set_activation(np.broadcast_to(F["init_activation"], (n_envs,) + F["init_activation"].shape).copy(),
+                           meta["deposit_strength"])
+    envs = (0, n_envs - 1)
+    for t, op in enumerate(F["ops"]):
+        ctx = "%s op %d kind %d" % (name, t, op)
+        if op == OP_STEP:
+            rot = np.broadcast_to(F["rot"][t], (n_envs, cfg.n_ants)) if F["has_rot"][t] else None
+            ph = np.broadcast_to(F["ph"][t], (n_envs, cfg.n_ants)) if F["has_ph"][t] else None
+            obs, ast, rew, done = env.step(rot, ph)
+            assert (_cpu(done) == F["done"][t]).all(), ctx
+        elif op == OP_OBSERVE:
+            obs, ast, rew = env.observe()
+        else:
+            env.update(np.broadcast_to(F["jitter"][t], (n_envs, cfg.n_ants)).copy())
+        if op != OP_UPDATE:
+            o, a, r = _cpu(obs), _cpu(ast), _cpu(rew)
+            for e in envs:
+                check_obs(cfg, o[e], F["obs"][t], ctx)
+                np.testing.assert_array_equal(a[e], F["agent_state"][t].astype(np.float32), err_msg=ctx)
+                np.testing.assert_array_equal(r[e], F["reward"][t].astype(np.float32), err_msg=ctx + " reward")
+        check_state(env, cfg, F, t, meta, ctx, envs, bool(F["stored"][t]))
+
+
+def test_fused_step_update_equals_two_calls(torch_mod):
+    """antsrl_step_update == antsrl_step then antsrl_update (the sweep is enqueued first there)."""
+    from antsrl_amd.batched import BatchedAntsEnv
+    from antsrl_amd import config as cm
+    cfg, init, F, meta = load_fixture("s03_walls_rocks", 2)
+    a, b = BatchedAntsEnv(cfg), BatchedAntsEnv(cfg)
+    a.reset(init)
+    b.reset(init)
+    for t in range(0, 40, 2):
+        rot = np.broadcast_to(F["rot"][t], (2, cfg.n_ants))
+        ph = np.broadcast_to(F["ph"][t], (2, cfg.n_ants))
+        jit = np.broadcast_to(F["jitter"][t + 1], (2, cfg.n_ants)).copy()
+        oa = [x.clone() for x in a.step(rot, ph)]
+        a.update(jit)
+        ob = b.step_update(rot, ph, jit)
+        for x, y in zip(oa, ob):
+            assert torch_mod.equal(x, y)
+    for which in (cm.S_ANTS_XYT, cm.S_PHERO, cm.S_FOOD, cm.S_EXPLORED, cm.S_ANTHILL_FOOD, cm.S_ROCK_CENTERS):
+        assert torch_mod.equal(a.read_state(which), b.read_state(which)), which
+    check_state(b, cfg, F, 39, meta, "fused", (0, 1), True)
+
+
+def _compare_with_oracle(torch_mod, cfg, init, steps, seed, jitter_mode):
+    from antsrl_amd.batched import BatchedAntsEnv
+    from antsrl_amd import config as cm
+    from antsrl_amd.synth import random_actions
+    from oracle.oracle import Oracle
+    env = BatchedAntsEnv(cfg)
+    env.reset(init)
+    orc = Oracle(cfg, init, n_threads=4)
+    rot, ph = random_actions(cfg, steps, seed)
+    rng = np.random.default_rng(seed)
+    E = cfg.n_envs
+    for t in range(steps):
+        ctx = "step %d" % t
+        obs, ast, rew, done = env.step(rot[t], ph[t])
+        o_obs, o_ast, o_rew, o_done = orc.step(rot[t], ph[t])
+        go = _cpu(obs)
+        for e in range(E):
+            check_obs(cfg, go[e], o_obs[e], ctx + " env %d" % e)
+        np.testing.assert_array_equal(_cpu(ast), o_ast.astype(np.float32), err_msg=ctx)
+        np.testing.assert_array_equal(_cpu(rew), o_rew.astype(np.float32), err_msg=ctx)
+        np.testing.assert_array_equal(_cpu(done), o_done, err_msg=ctx)
+        jit = rng.random((E, cfg.n_ants)) if jitter_mode == "injected" else None
+        env.update(jit)
+        orc.update(jit)
+        xyt = _cpu(env.read_state(cm.S_ANTS_XYT))
+        np.testing.assert_allclose(xyt, orc.ants_xyt, rtol=0, atol=XY_ATOL, err_msg=ctx)
+        np.testing.assert_array_equal(np.floor(xyt[..., :2]), np.floor(orc.ants_xyt[..., :2]), err_msg=ctx)
+        np.testing.assert_array_equal(_cpu(env.read_state(cm.S_HOLDING)), orc.holding, err_msg=ctx)
+        np.testing.assert_array_equal(_cpu(env.read_state(cm.S_FOOD)), orc.food, err_msg=ctx)
+        np.testing.assert_array_equal(_cpu(env.read_state(cm.S_ANTHILL_FOOD)), orc.anthill_food, err_msg=ctx)
+    np.testing.assert_array_equal(_cpu(env.read_state(cm.S_EXPLORED)), orc.explored)
+    np.testing.assert_array_equal(_cpu(env.read_state(cm.S_MANDIBLES)), orc.mandibles)
+    ok = phero_close(_cpu(env.read_state(cm.S_PHERO)), orc.phero, threshold=cfg.phero_threshold)
+    assert ok.all(), "pheromone: %d cells off" % (~ok).sum()
+    if cfg.n_rocks:
+        np.testing.assert_allclose(_cpu(env.read_state(cm.S_ROCK_CENTERS)), orc.rock_centers, rtol=0, atol=XY_ATOL)
+    return env, orc
+
+
+def test_bench_config_vs_oracle(torch_mod):
+    """BASELINE config 3 shape (256x256, 512 ants, 8 rocks, walls, food) on a few envs, with the
+    built-in counter-based wall jitter (device and oracle implement the same generator)."""
+    from antsrl_amd.config import make_cfg
+    from antsrl_amd.synth import synth_init
+    cfg = make_cfg(6, 512, 256, 256, n_rocks=8, deposit_strength=256.0)
+    _compare_with_oracle(torch_mod, cfg, synth_init(cfg, seed=77), steps=12, seed=5, jitter_mode="builtin")
+
+
+def test_config2_vs_oracle_injected_jitter(torch_mod):
+    from antsrl_amd.config import make_cfg
+    from antsrl_amd.synth import synth_init
+    cfg = make_cfg(4, 256, 256, 256, n_rocks=0)
+    _compare_with_oracle(torch_mod, cfg, synth_init(cfg, seed=3), steps=10, seed=6, jitter_mode="injected")
+
+
+def test_config4_shape_radius3_vs_oracle(torch_mod):
+    """512x512 grid, 1024 ants, radius-3 diffusion filter (BASELINE config 4 per-env shape)."""
+    from antsrl_amd.config import make_cfg
+    from antsrl_amd.synth import synth_init
+    ax = np.arange(-3, 4)
+    g = np.exp(-(ax[:, None] ** 2 + ax[None, :] ** 2) / 4.5)
+    g = g / g.sum() * 0.999
+    cfg = make_cfg(2, 1024, 512, 512, filt=g, deposit_strength=256.0)
+    _compare_with_oracle(torch_mod, cfg, synth_init(cfg, seed=11), steps=6, seed=8, jitter_mode="builtin")
+
+
+def test_small_and_odd_shapes(torch_mod):
+    """Ragged sizes: non-power-of-two grid whose cell count is not a multiple of 32, ant count
+    not a multiple of the wave, 1 ant, no mask, 5x5 perception, a single pheromone channel seen."""
+    from antsrl_amd import config as cm
+    from antsrl_amd.synth import synth_init
+    for (E, N, W, H, kw) in [
+        (2, 70, 37, 51, dict(n_rocks=2)),
+        (3, 1, 16, 16, dict()),
+        (2, 33, 40, 24, dict(mask=None, perception_radius=2)),
+        (1, 100, 64, 64, dict(channels=[(cm.CH_FOOD, 0), (cm.CH_PHERO, 1), (cm.CH_ANTHILL, 0)],
+                              reward_kind=cm.REWARD_ALL, fct_explore_holding=0.5)),
+        (2, 50, 33, 33, dict(n_phero=1, channels=[(cm.CH_ANTS, 0), (cm.CH_PHERO, 0), (cm.CH_WALLS, 0)])),
+    ]:
+        cfg = cm.make_cfg(E, N, W, H, **kw)
+        init = synth_init(cfg, seed=5, n_food_discs=6, food_rmin=2, food_rmax=5)
+        if cfg.n_phero != 2:
+            # pheromone actions need two channels (ants.py:89-96): drive with rotation only
+            from antsrl_amd.batched import BatchedAntsEnv
+            from oracle.oracle import Oracle
+            env, orc = BatchedAntsEnv(cfg), Oracle(cfg, init)
+            env.reset(init)
+            rng = np.random.default_rng(0)
+            for t in range(8):
+                rot = rng.integers(-1, 2, (E, N), dtype=np.int8)
+                obs, ast, rew, done = env.step(rot, None)
+                o_obs, o_ast, o_rew, o_done = orc.step(rot, None)
+                for e in range(E):
+                    check_obs(cfg, _cpu(obs)[e], o_obs[e], "1-phero step %d" % t)
+                np.testing.assert_array_equal(_cpu(rew), o_rew.astype(np.float32))
+                env.update(None)
+                orc.update(None)
+            continue
+        _compare_with_oracle(torch_mod, cfg, init, steps=8, seed=2, jitter_mode="injected")
+
+
+def test_known_answers(torch_mod):
+    """Hand-derived cases for the semantics catalogued in SURVEY.md §8(a)."""
+    from antsrl_amd import config as cm
+    from antsrl_amd.batched import BatchedAntsEnv
+    W = H = 16
+    N = 4
+    cfg = cm.make_cfg(1, N, W, H, deposit_strength=256.0, max_time=3)
+    walls = np.zeros((1, W, H), np.uint8)
+    food = np.zeros((1, W, H), np.float32)
+    food[0, 5, 5] = 3.0  # two ants on one food cell: both take min(5,3)=3, cell rewritten once
+    xyt = np.array([[[5.2, 5.7, 0.0], [5.9, 5.1, 1.0], [9.5, 9.5, 2.0], [9.5, 9.5, 3.0]]])
+    init = dict(ants_xyt=xyt, seed=np.full((1, N), 0.25), walls=walls, food=food,
+                anthill_xyr=np.array([[12, 12, 1]], np.int32))
+    env = BatchedAntsEnv(cfg)
+    env.reset(init)
+    obs, ast, rew, done = env.step(np.zeros((1, N), np.int8), np.array([[1, 2, 1, 2]], np.int8))
+    assert _cpu(ast)[0, :, 0].tolist() == [3.0, 3.0, 0.0, 0.0]      # both gained (ants.py:111,117)
+    assert _cpu(env.read_state(cm.S_FOOD))[0, 5, 5] == 0.0           # decremented once, last writer
+    assert _cpu(done)[0] == 0
+    env.update(None)
+    # deposit: ants 2 and 3 share cell (10,9)/(9,..)? use their floor cells; last ant wins per cell
+    xy = np.floor(_cpu(env.read_state(cm.S_ANTS_XYT))[0, :, :2]).astype(int)
+    ph = _cpu(env.read_state(cm.S_PHERO))[0]
+    act = _cpu(env.read_state(cm.S_ACTIVATION))[0]
+    for i in range(N):
+        last = max(j for j in range(N) if (xy[j] == xy[i]).all())
+        for c in range(2):
+            assert ph[c, xy[i][0], xy[i][1]] == min(255.0, act[last, c]), (i, c)
+    # done only on the step where timestep == max_time (RL_api.py:200); timestep is now 2
+    _, _, _, done = env.step(None, None)
+    assert _cpu(done)[0] == 0
+    env.update(None)
+    _, _, _, done = env.step(None, None)
+    assert _cpu(done)[0] == 1
+    env.update(None)
+    _, _, _, done = env.step(None, None)
+    assert _cpu(done)[0] == 0
+    # masked perception cells are exactly -1; presence channel is 0/1
+    o = _cpu(obs)[0]
+    mask = cm.mask_array(cfg)
+    assert (o[:, ~mask, :] == -1).all()
+    assert set(np.unique(o[:, mask, 0])) <= {0.0, 1.0}
