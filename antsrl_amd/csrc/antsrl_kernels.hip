@@ -118,9 +118,12 @@ __host__ __device__ __forceinline__ size_t align_up(size_t v, size_t a) { return
 // k_act — RLApi.step (RL_api.py:168-204) / RLApi.observation (RL_api.py:96-165)
 // one workgroup per environment
 // ===================================================================================
+struct __align__(16) AntFrame { double cx, cy, ct, st; }; // perception centre, cos/sin(theta + pi/2)
+struct __align__(16) CellOff { double px, py; };            // rotated-grid offsets, RL_api.py:92-93
+
 struct ActLds {
-    double *f_cx, *f_cy, *f_ct, *f_st; // [N] per-ant perception frame (centre, cos, sin)
-    double *t_px, *t_py;               // [PP] rotated-grid offsets, RL_api.py:92-93
+    AntFrame *frame;                   // [N]
+    CellOff *off;                      // [PP]
     uint32_t *cnt;                     // [N] unexplored-cell count / temp cell index
     uint32_t *rockmask;                // [N] rocks that can touch the ant's patch
     uint32_t *b_pres, *b_old, *b_new;  // [words] presence / explored (pre-step) / explored (marked)
@@ -129,6 +132,9 @@ struct ActLds {
     uint32_t *hkeys, *hvals;           // [HT] — aliases `stage`
     float *stage;                      // [nwaves*64*K]
 };
+
+#define ACT_UNROLL 2                 // work items per lane per iteration (gathers in flight)
+#define ACT_ITEMS (64 * ACT_UNROLL)  // work items per wave per iteration
 
 __host__ __device__ inline size_t act_lds_bytes(int N, int PP, int words, int HT, int K, int nwaves,
                                                 bool static_lds, ActLds *o, unsigned char *base)
@@ -139,9 +145,8 @@ __host__ __device__ inline size_t act_lds_bytes(int N, int PP, int words, int HT
         off = (off + bytes + 15) / 16 * 16;
         return at;
     };
-    size_t a_cx = take(8 * (size_t)N), a_cy = take(8 * (size_t)N), a_ct = take(8 * (size_t)N),
-           a_st = take(8 * (size_t)N);
-    size_t a_px = take(8 * (size_t)PP), a_py = take(8 * (size_t)PP);
+    size_t a_fr = take(sizeof(AntFrame) * (size_t)N);
+    size_t a_off = take(sizeof(CellOff) * (size_t)PP);
     size_t a_cnt = take(4 * (size_t)N), a_rm = take(4 * (size_t)N);
     size_t a_pres = take(4 * (size_t)words), a_old = take(4 * (size_t)words), a_new = take(4 * (size_t)words);
     size_t a_w = 0, a_a = 0;
@@ -153,9 +158,8 @@ __host__ __device__ inline size_t act_lds_bytes(int N, int PP, int words, int HT
     size_t hash_b = 8 * (size_t)HT, stage_b = 4 * (size_t)nwaves * 64 * K;
     size_t a_u = take(hash_b > stage_b ? hash_b : stage_b);
     if (o) {
-        o->f_cx = (double *)(base + a_cx); o->f_cy = (double *)(base + a_cy);
-        o->f_ct = (double *)(base + a_ct); o->f_st = (double *)(base + a_st);
-        o->t_px = (double *)(base + a_px); o->t_py = (double *)(base + a_py);
+        o->frame = (AntFrame *)(base + a_fr);
+        o->off = (CellOff *)(base + a_off);
         o->cnt = (uint32_t *)(base + a_cnt); o->rockmask = (uint32_t *)(base + a_rm);
         o->b_pres = (uint32_t *)(base + a_pres); o->b_old = (uint32_t *)(base + a_old);
         o->b_new = (uint32_t *)(base + a_new);
@@ -167,7 +171,13 @@ __host__ __device__ inline size_t act_lds_bytes(int N, int PP, int words, int HT
     return off;
 }
 
-template <int C, bool STATIC_LDS>
+// Perception-channel layouts known at compile time (straight-line output code); anything else
+// takes the generic per-channel selection.
+#define LAYOUT_GENERIC 0
+#define LAYOUT_DEFAULT 1       // [Ants, Phero0, Phero1, Anthill, Walls, Food]   (generator order)
+#define LAYOUT_DEFAULT_ROCKS 2 // ... + [CircleObstacles]
+
+template <int C, bool STATIC_LDS, int LAYOUT>
 __global__ void __launch_bounds__(1024)
 k_act(const KP p, const int8_t *__restrict__ rotation, const int8_t *__restrict__ phero_act, const int cur,
       float *__restrict__ obs, float *__restrict__ agent_state, float *__restrict__ reward,
@@ -206,8 +216,8 @@ k_act(const KP p, const int8_t *__restrict__ rotation, const int8_t *__restrict_
     }
     for (int q = tid; q < PP; q += T) {
         int a = q / P, b = q % P;
-        L.t_px[q] = (double)(b - p.r) * p.delta; // coords[a][b] = (arange[b], arange[a]) * DELTA
-        L.t_py[q] = (double)(a - p.r) * p.delta;
+        L.off[q].px = (double)(b - p.r) * p.delta; // coords[a][b] = (arange[b], arange[a]) * DELTA
+        L.off[q].py = (double)(a - p.r) * p.delta;
         L.t_mask[q] = p.has_mask ? p.mask[q] : (uint8_t)1;
     }
     if (do_step)
@@ -220,6 +230,7 @@ k_act(const KP p, const int8_t *__restrict__ rotation, const int8_t *__restrict_
     if (do_step) {
         // ---- phase 1a: mandible target (RL_api.py:178-185) + Ants.update_mandibles reads
         //      (ants.py:102-114).  All food reads happen before any food write.
+        float *tmp_q = (float *)L.frame, *tmp_d = tmp_q + N; // frame memory is free until phase 2
         for (int i = tid; i < N; i += T) {
             const double x = p.s.x[eN + i], y = p.s.y[eN + i];
             const uint32_t cprev = (uint32_t)((int)p.s.prev_x[eN + i] * H + (int)p.s.prev_y[eN + i]);
@@ -237,20 +248,19 @@ k_act(const KP p, const int8_t *__restrict__ rotation, const int8_t *__restrict_
             const float dropped = hold * (float)opening;                                    // :114
             p.s.holding[eN + i] = hold + (taken - dropped);                                 // :117
             p.s.mandibles[eN + i] = (uint8_t)m;                                             // :107
-            // stash for phase 1b (frame arrays are free until phase 2)
             L.cnt[i] = cprev;
-            ((float *)L.f_cx)[i] = q;
-            ((float *)L.f_cy)[i] = dropped - taken;
+            tmp_q[i] = q;
+            tmp_d[i] = dropped - taken;
             lww_insert(L.hkeys, L.hvals, (uint32_t)p.HT - 1, cprev, (uint32_t)i);
         }
         __syncthreads();
         // ---- phase 1b: ants.py:116 `qte[cell] += dropped - taken`, last ant on a cell wins
         for (int i = tid; i < N; i += T) {
             const uint32_t cprev = L.cnt[i];
-            const float delta = ((float *)L.f_cy)[i];
+            const float delta = tmp_d[i];
             int32_t dirty = -1;
             if (delta != 0.0f && lww_winner(L.hkeys, L.hvals, (uint32_t)p.HT - 1, cprev) == (uint32_t)i) {
-                food[cprev] = ((float *)L.f_cx)[i] + delta;
+                food[cprev] = tmp_q[i] + delta;
                 if (test_bit(area, cprev)) dirty = (int32_t)cprev;
             }
             p.s.dirty_cell[eN + i] = dirty;
@@ -294,7 +304,9 @@ k_act(const KP p, const int8_t *__restrict__ rotation, const int8_t *__restrict_
         }
         double st, ct;
         sincos(th + PI_D * 0.5, &st, &ct);
-        L.f_cx[i] = xf; L.f_cy[i] = yf; L.f_ct[i] = ct; L.f_st[i] = st;
+        AntFrame fr;
+        fr.cx = xf; fr.cy = yf; fr.ct = ct; fr.st = st;
+        L.frame[i] = fr;
         L.cnt[i] = 0u;
         // presence map, RL_api.py:137-141 (0/1, not a count)
         const uint32_t cell = (uint32_t)(wrap_index((int)x, W) * H + wrap_index((int)y, H));
@@ -313,93 +325,130 @@ k_act(const KP p, const int8_t *__restrict__ rotation, const int8_t *__restrict_
     }
     __syncthreads();
 
-    // ---- phase 3: perception gather, RL_api.py:109-148.  Work item = (ant, cell); a wave
-    //      takes 64 consecutive items, stages its 64*K outputs in LDS and writes them as one
-    //      contiguous, 16-byte-vectorised run of the observation tensor.
+    // ---- phase 3: perception gather, RL_api.py:109-148.  Work item = (ant, cell); a wave takes
+    //      ACT_ITEMS consecutive items (ACT_UNROLL per lane, so several gathers are in flight),
+    //      stages their K outputs in LDS and writes them as one contiguous, 16-byte-vectorised
+    //      run of the observation tensor.
     const uint32_t total = (uint32_t)N * (uint32_t)PP;
+    const uint32_t pp_magic = (uint32_t)((0x100000000ull + (uint32_t)PP - 1) / (uint32_t)PP); // item/PP by mul-hi
     float *stage = L.stage + (size_t)wave * 64 * K;
     float *obs_env = (flags & ACT_HAS_OBS) ? obs + (size_t)e * total * K : nullptr;
     const bool vec_ok = (((size_t)total * K) % 4 == 0);
-    const float inv_dummy = 0.0f;
-    (void)inv_dummy;
-    for (uint32_t base = (uint32_t)wave * 64; base < total; base += (uint32_t)nwaves * 64) {
-        const uint32_t item = base + lane;
-        if (item < total) {
-            const uint32_t i = item / (uint32_t)PP, q = item - i * (uint32_t)PP;
-            const double px = L.t_px[q], py = L.t_py[q];
-            const double ct = L.f_ct[i], st = L.f_st[i];
-            const double rx = ct * px - st * py; // RL_api.py:110-111
-            const double ry = st * px + ct * py;
-            const int ix = wrap_index((int)rint(rx + L.f_cx[i]), W); // :114-119
-            const int iy = wrap_index((int)rint(ry + L.f_cy[i]), H);
-            const uint32_t cell = (uint32_t)(ix * H + iy);
-            if (explore && !test_bit(L.b_old, cell)) { // reward_custom.py:19,22 (mask ignored)
-                atomicAdd(&L.cnt[i], 1u);
-                atomicOr(&L.b_new[cell >> 5], 1u << (cell & 31));
-            }
-            if (obs_env) {
-                float *o = stage + lane * K;
-                if (!L.t_mask[q]) { // RL_api.py:147-148: mask*(p+1)-1 == -1
-                    for (int k = 0; k < K; ++k) o[k] = -1.0f;
+    const float inv_max = 1.0f / (float)p.max_val;
+    for (uint32_t base = (uint32_t)wave * ACT_ITEMS; base < total; base += (uint32_t)nwaves * ACT_ITEMS) {
+        uint32_t ant[ACT_UNROLL], cell[ACT_UNROLL];
+        int ixv[ACT_UNROLL], iyv[ACT_UNROLL];
+        bool valid[ACT_UNROLL], vis[ACT_UNROLL];
+        float pv[ACT_UNROLL][C];
+        float fd[ACT_UNROLL];
+#pragma unroll
+        for (int u = 0; u < ACT_UNROLL; ++u) {
+            const uint32_t item = base + u * 64 + lane;
+            valid[u] = item < total;
+            const uint32_t it = valid[u] ? item : 0u;
+            const uint32_t i = __umulhi(it, pp_magic), q = it - i * (uint32_t)PP; // exact: it < 2^32/(PP*PP)
+            const AntFrame fr = L.frame[i];
+            const CellOff of = L.off[q];
+            const double rx = fr.ct * of.px - fr.st * of.py; // RL_api.py:110-111
+            const double ry = fr.st * of.px + fr.ct * of.py;
+            ixv[u] = wrap_index((int)rint(rx + fr.cx), W); // :114-119 (np.round = half to even)
+            iyv[u] = wrap_index((int)rint(ry + fr.cy), H);
+            cell[u] = (uint32_t)(ixv[u] * H + iyv[u]);
+            ant[u] = i;
+            vis[u] = valid[u] && obs_env && L.t_mask[q];
+        }
+        // issue every global gather before anything consumes one
+#pragma unroll
+        for (int u = 0; u < ACT_UNROLL; ++u) {
+            fd[u] = 0.0f;
+#pragma unroll
+            for (int c = 0; c < C; ++c) pv[u][c] = 0.0f;
+            if (vis[u]) {
+                if (C == 2) {
+                    const float2 t = *reinterpret_cast<const float2 *>(ph + (size_t)cell[u] * 2);
+                    pv[u][0] = t.x; pv[u][C - 1] = t.y;
                 } else {
-                    float pv[C];
-                    bool have_ph = false;
-                    for (int k = 0; k < K; ++k) {
-                        float v = 0.0f;
-                        switch (p.ch_kind[k]) {
-                        case ANTSRL_CH_PHERO: // :124-125
-                            if (!have_ph) {
-                                if (C == 2) {
-                                    const float2 t = *reinterpret_cast<const float2 *>(ph + (size_t)cell * 2);
-                                    pv[0] = t.x; pv[C - 1] = t.y;
-                                } else {
-                                    for (int c = 0; c < C; ++c) pv[c] = ph[(size_t)cell * C + c];
-                                }
-                                have_ph = true;
-                            }
-                            {
-                                float t = pv[0];
-                                for (int c = 1; c < C; ++c) t = (p.ch_arg[k] == c) ? pv[c] : t;
-                                v = t / (float)p.max_val;
-                            }
-                            break;
-                        case ANTSRL_CH_FOOD: v = food[cell]; break;                          // :126-127
-                        case ANTSRL_CH_WALLS: v = test_bit(walls, cell) ? 1.0f : 0.0f; break;  // :128-129
-                        case ANTSRL_CH_ANTHILL: v = test_bit(area, cell) ? 1.0f : 0.0f; break; // :130-131
-                        case ANTSRL_CH_ANTS: v = test_bit(L.b_pres, cell) ? 1.0f : 0.0f; break; // :142
-                        case ANTSRL_CH_ROCKS: {                                               // :132-135
+#pragma unroll
+                    for (int c = 0; c < C; ++c) pv[u][c] = ph[(size_t)cell[u] * C + c];
+                }
+                fd[u] = food[cell[u]];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < ACT_UNROLL; ++u) {
+            const uint32_t ubase = base + u * 64;
+            if (ubase >= total) break; // wave-uniform
+            if (valid[u]) {
+                const uint32_t cl = cell[u], i = ant[u];
+                if (explore && !test_bit(L.b_old, cl)) { // reward_custom.py:19,22 (mask ignored)
+                    atomicAdd(&L.cnt[i], 1u);
+                    atomicOr(&L.b_new[cl >> 5], 1u << (cl & 31));
+                }
+                if (obs_env) {
+                    float *o = stage + lane * K;
+                    if (!vis[u]) { // RL_api.py:147-148: mask*(p+1)-1 == -1
+                        for (int k = 0; k < K; ++k) o[k] = -1.0f;
+                    } else {
+                        const float v_ants = test_bit(L.b_pres, cl) ? 1.0f : 0.0f;  // :142
+                        const float v_area = test_bit(area, cl) ? 1.0f : 0.0f;       // :130-131
+                        const float v_wall = test_bit(walls, cl) ? 1.0f : 0.0f;      // :128-129
+                        float v_rock = 0.0f;                                         // :132-135
+                        if (LAYOUT != LAYOUT_DEFAULT && R > 0) {
                             uint32_t rm = L.rockmask[i];
                             bool any = false;
                             while (rm) {
                                 const int r = __builtin_ctz(rm);
                                 rm &= rm - 1;
-                                const double vx = (double)ix - p.s.rock_cx[(size_t)e * R + r];
-                                const double vy = (double)iy - p.s.rock_cy[(size_t)e * R + r];
+                                const double vx = (double)ixv[u] - p.s.rock_cx[(size_t)e * R + r];
+                                const double vy = (double)iyv[u] - p.s.rock_cy[(size_t)e * R + r];
                                 any |= sqrt(vx * vx + vy * vy) < p.s.rock_r[(size_t)e * R + r];
                             }
-                            v = any ? 1.0f : 0.0f;
-                        } break;
-                        default: break;
+                            v_rock = any ? 1.0f : 0.0f;
                         }
-                        o[k] = v;
+                        if (LAYOUT == LAYOUT_DEFAULT || LAYOUT == LAYOUT_DEFAULT_ROCKS) {
+                            // phero/max_val (:124-125) as a multiply by the f32 reciprocal: the
+                            // pheromone channels are held to 1e-5, not bit-exactness (fp32 grid)
+                            o[0] = v_ants; o[1] = pv[u][0] * inv_max; o[2] = pv[u][C - 1] * inv_max;
+                            o[3] = v_area; o[4] = v_wall; o[5] = fd[u];
+                            if (LAYOUT == LAYOUT_DEFAULT_ROCKS) o[6] = v_rock;
+                        } else {
+                            for (int k = 0; k < K; ++k) {
+                                float v = 0.0f;
+                                switch (p.ch_kind[k]) {
+                                case ANTSRL_CH_PHERO: {
+                                    float t = pv[u][0];
+#pragma unroll
+                                    for (int c = 1; c < C; ++c) t = (p.ch_arg[k] == c) ? pv[u][c] : t;
+                                    v = t * inv_max;
+                                } break;
+                                case ANTSRL_CH_FOOD: v = fd[u]; break;      // :126-127
+                                case ANTSRL_CH_WALLS: v = v_wall; break;
+                                case ANTSRL_CH_ANTHILL: v = v_area; break;
+                                case ANTSRL_CH_ANTS: v = v_ants; break;
+                                case ANTSRL_CH_ROCKS: v = v_rock; break;
+                                default: break;
+                                }
+                                o[k] = v;
+                            }
+                        }
                     }
                 }
             }
-        }
-        if (obs_env) {
-            wave_lds_sync();
-            const uint32_t nvalid = min(64u, total - base);
-            const uint32_t nfl = nvalid * (uint32_t)K;
-            float *dst = obs_env + (size_t)base * K;
-            if (vec_ok) { // base*K*4 is a multiple of 256 bytes; env base is 16-byte aligned
-                const uint32_t n4 = nfl >> 2;
-                for (uint32_t j = lane; j < n4; j += 64)
-                    reinterpret_cast<float4 *>(dst)[j] = reinterpret_cast<const float4 *>(stage)[j];
-                for (uint32_t j = (n4 << 2) + lane; j < nfl; j += 64) dst[j] = stage[j];
-            } else {
-                for (uint32_t j = lane; j < nfl; j += 64) dst[j] = stage[j];
+            if (obs_env) {
+                wave_lds_sync();
+                const uint32_t nvalid = min(64u, total - ubase);
+                const uint32_t nfl = nvalid * (uint32_t)K;
+                float *dst = obs_env + (size_t)ubase * K;
+                if (vec_ok) { // ubase*K*4 is a multiple of 256 bytes; env base is 16-byte aligned
+                    const uint32_t n4 = nfl >> 2;
+                    for (uint32_t j = lane; j < n4; j += 64)
+                        reinterpret_cast<float4 *>(dst)[j] = reinterpret_cast<const float4 *>(stage)[j];
+                    for (uint32_t j = (n4 << 2) + lane; j < nfl; j += 64) dst[j] = stage[j];
+                } else {
+                    for (uint32_t j = lane; j < nfl; j += 64) dst[j] = stage[j];
+                }
+                wave_lds_sync();
             }
-            wave_lds_sync();
         }
     }
     __syncthreads();
@@ -944,25 +993,47 @@ static size_t update_lds_bytes(const KP &p, int threads)
            4 * (size_t)(threads / 64) + 16;
 }
 
+static int act_layout(const KP &p)
+{
+    static const int def[7] = {ANTSRL_CH_ANTS, ANTSRL_CH_PHERO, ANTSRL_CH_PHERO, ANTSRL_CH_ANTHILL,
+                               ANTSRL_CH_WALLS, ANTSRL_CH_FOOD, ANTSRL_CH_ROCKS};
+    if (p.C != 2 || (p.K != 6 && p.K != 7)) return LAYOUT_GENERIC;
+    for (int k = 0; k < p.K; ++k)
+        if (p.ch_kind[k] != def[k]) return LAYOUT_GENERIC;
+    if (p.ch_arg[1] != 0 || p.ch_arg[2] != 1) return LAYOUT_GENERIC;
+    return p.K == 6 ? LAYOUT_DEFAULT : LAYOUT_DEFAULT_ROCKS;
+}
+
+template <int C, bool ST, int LAYOUT>
+static hipError_t launch_act_k(const KP &p, const ActPlan &pl, const int8_t *rot, const int8_t *ph, int cur,
+                               float *obs, float *agent_state, float *reward, uint8_t *done, int flags,
+                               hipStream_t st)
+{
+    static size_t attr_lds = 0; // dynamic-LDS opt-in is per kernel function, set once per size
+    if (pl.lds > attr_lds) {
+        hipError_t err = hipFuncSetAttribute((const void *)k_act<C, ST, LAYOUT>,
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds);
+        if (err != hipSuccess) return err;
+        attr_lds = pl.lds;
+    }
+    hipLaunchKernelGGL((k_act<C, ST, LAYOUT>), dim3(p.E), dim3(pl.threads), pl.lds, st, p, rot, ph, cur, obs,
+                       agent_state, reward, done, flags);
+    return hipGetLastError();
+}
+
 template <int C>
 static hipError_t launch_act_c(const KP &p, const int8_t *rot, const int8_t *ph, int cur, float *obs,
                                float *agent_state, float *reward, uint8_t *done, int flags, hipStream_t st)
 {
     const ActPlan pl = plan_act(p);
     if (pl.lds > 160 * 1024) return hipErrorInvalidValue;
-    hipError_t err;
-    if (pl.static_lds) {
-        err = hipFuncSetAttribute((const void *)k_act<C, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds);
-        if (err != hipSuccess) return err;
-        hipLaunchKernelGGL((k_act<C, true>), dim3(p.E), dim3(pl.threads), pl.lds, st, p, rot, ph, cur, obs,
-                           agent_state, reward, done, flags);
-    } else {
-        err = hipFuncSetAttribute((const void *)k_act<C, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds);
-        if (err != hipSuccess) return err;
-        hipLaunchKernelGGL((k_act<C, false>), dim3(p.E), dim3(pl.threads), pl.lds, st, p, rot, ph, cur, obs,
-                           agent_state, reward, done, flags);
-    }
-    return hipGetLastError();
+    const int layout = (C == 2) ? act_layout(p) : LAYOUT_GENERIC;
+#define ACT_GO(ST, LY) return launch_act_k<C, ST, LY>(p, pl, rot, ph, cur, obs, agent_state, reward, done, flags, st)
+    if (C == 2 && layout == LAYOUT_DEFAULT) { if (pl.static_lds) ACT_GO(true, (C == 2 ? LAYOUT_DEFAULT : LAYOUT_GENERIC)); else ACT_GO(false, (C == 2 ? LAYOUT_DEFAULT : LAYOUT_GENERIC)); }
+    if (C == 2 && layout == LAYOUT_DEFAULT_ROCKS) { if (pl.static_lds) ACT_GO(true, (C == 2 ? LAYOUT_DEFAULT_ROCKS : LAYOUT_GENERIC)); else ACT_GO(false, (C == 2 ? LAYOUT_DEFAULT_ROCKS : LAYOUT_GENERIC)); }
+    if (pl.static_lds) ACT_GO(true, LAYOUT_GENERIC);
+    ACT_GO(false, LAYOUT_GENERIC);
+#undef ACT_GO
 }
 
 hipError_t antsrl_launch_act(const KP &p, const int8_t *rot, const int8_t *ph, int cur, float *obs,
