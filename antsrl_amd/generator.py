@@ -1,0 +1,153 @@
+"""Episode "reset": host-side counterpart of generator/environment_generator.py and
+generator/map_generators.py.
+
+EnvironmentGenerator.generate(rl_api) draws the initial state with the SAME calls, in the same
+order, from the same global `random` / `np.random` streams as the reference
+(environment_generator.py:52-106), so an equal seed gives an identical initial state
+(tests/test_generator.py pins this against the golden fixtures).  It then uploads the state
+once (antsrl_reset) and wires the RLApi / Environment views.
+
+Extensions over the reference (none changes its behaviour for the reference's arguments):
+  * n_envs > 1 builds a batch; env e is drawn with seed + e (seed=None: fresh randomness each);
+  * n_rocks > 0 works.  The reference's rock branch raises NameError (`n_rocks` undefined at
+    environment_generator.py:83-84); this follows its evident intent (self.n_rocks).
+PerlinGenerator is not provided: it needs the third-party `noise` package (absent); walls are
+just an input bitmap to the path, any object with .generate(w, h) -> bool[w, h] works.
+"""
+from __future__ import annotations
+
+import random
+
+import numpy as np
+
+from . import config as cm
+from .rl_api import (Ants, Anthill, CircleObstacles, Environment, Food, Pheromone, RLApi, Walls)
+
+PHERO_COLORS = [(255, 64, 0), (64, 64, 255), (100, 255, 100)]  # environment_generator.py:12-16
+
+
+class CirclesGenerator:  # generator/map_generators.py:28-46
+    def __init__(self, n_circles, min_radius, max_radius):
+        self.n_circles, self.min_radius, self.max_radius = n_circles, min_radius, max_radius
+
+    def generate(self, w, h):
+        gen = np.zeros((w, h), dtype=bool)
+        for _ in range(self.n_circles):
+            radius = int(random.random() * (self.max_radius - self.min_radius) + self.min_radius)
+            xc = int(random.random() * (w - 2 * radius) + radius)
+            yc = int(random.random() * (h - 2 * radius) + radius)
+            xs = np.arange(xc - radius, xc + radius + 1)
+            ys = np.arange(yc - radius, yc + radius + 1)
+            # ((xc-x)**2 + (yc-y)**2) ** 0.5 <= radius with integer operands
+            inside = (xc - xs)[:, None] ** 2 + (yc - ys)[None, :] ** 2 <= radius * radius
+            gx, gy = np.nonzero(inside)
+            gen[xs[gx], ys[gy]] = True  # negative indices wrap exactly like the reference's gen[x, y]
+        return gen
+
+
+class BernoulliGenerator:
+    """Independent wall cells with the given density, drawn from np.random (a stand-in for
+    PerlinGenerator)."""
+
+    def __init__(self, density=0.05):
+        self.density = density
+
+    def generate(self, w, h):
+        return np.random.random((w, h)) < self.density
+
+
+class EmptyGenerator:
+    def generate(self, w, h):
+        return np.zeros((w, h), dtype=bool)
+
+
+class PerlinGenerator:  # generator/map_generators.py:9-25
+    def __init__(self, *a, **k):
+        raise NotImplementedError("PerlinGenerator needs the third-party `noise` package, which is outside "
+                                  "the hot path; pass any object with .generate(w, h) -> bool[w, h]")
+
+
+class EnvironmentGenerator:  # generator/environment_generator.py:19-106
+    def __init__(self, w, h, n_ants, n_pheromones, n_rocks, food_generator, walls_generator, max_steps,
+                 seed=None, n_envs=1):
+        self.w, self.h, self.n_ants = w, h, n_ants
+        self.n_pheromones, self.n_rocks = n_pheromones, n_rocks
+        self.food_generator, self.walls_generator = food_generator, walls_generator
+        self.perception_mask = cm.DEFAULT_MASK.astype(bool)  # :35-41
+        self.perception_shift = 4                            # :43
+        self.max_steps, self.seed, self.n_envs = max_steps, seed, n_envs
+
+    def setup_perception(self, new_mask, new_shift):  # :48-50
+        self.perception_mask, self.perception_shift = new_mask, new_shift
+
+    def _draw_one(self, seed):
+        """One environment's initial arrays; RNG call order of environment_generator.py:52-94."""
+        w, h, n = self.w, self.h, self.n_ants
+        if seed is not None:
+            random.seed(seed)          # :54
+            np.random.seed(seed * 5)   # :55
+        ax = int(random.random() * w * 0.5 + w * 0.25)                     # :61
+        ay = int(random.random() * h * 0.5 + h * 0.25)                     # :62
+        ar = int(random.random() * min(w, h) * 0.05 + min(w, h) * 0.05)    # :63
+        xs, ys = np.meshgrid(np.arange(w), np.arange(h), indexing="ij")
+        area = (ax - xs) ** 2 + (ay - ys) ** 2 <= ar * ar                  # anthill.py:28-33
+        walls = np.array(self.walls_generator.generate(w, h)).astype(bool) # :66
+        walls[area] = False                                                # :67
+        food = np.array(self.food_generator.generate(w, h)).astype(float)  # :71, food.py:15
+        food *= (1 - walls)                                                # :72
+        rocks = np.zeros((0, 4))
+        if self.n_rocks > 0:                                               # :76-85
+            c = np.random.random((self.n_rocks, 2))
+            c[:, 0] *= w * 0.75
+            c[:, 1] *= h * 0.25
+            c[:, 0] += w * 0.25
+            c[:, 1] += h * 0.25
+            rad = np.random.random(self.n_rocks) * 5 + 5
+            wgt = np.random.random(self.n_rocks) * 50 + 50
+            rocks = np.concatenate([c, rad[:, None], wgt[:, None]], axis=1)
+        ang = np.random.random(n) * 2 * np.pi                              # :87
+        dist = np.random.random(n) * ar * 0.8                              # :88
+        x = np.cos(ang) * dist + ax                                        # :89
+        y = np.sin(ang) * dist + ay                                        # :90
+        t = np.random.random(n) * 2 * np.pi                                # :91
+        seed_arr = np.random.random(n)                                     # Ants.__init__, ants.py:41
+        return dict(ants_xyt=np.array([x, y, t]).T, seed=seed_arr, walls=walls.astype(np.uint8),
+                    food=food.astype(np.float32), anthill_xyr=np.array([ax, ay, ar], np.int32), rocks=rocks)
+
+    def draw(self):
+        """Initial state of the whole batch as env-major numpy arrays (AntsInit layout)."""
+        per = [self._draw_one(None if self.seed is None else self.seed + e) for e in range(self.n_envs)]
+        init = {k: np.stack([p[k] for p in per]) for k in per[0]}
+        if self.n_rocks == 0:
+            init.pop("rocks")
+        return init
+
+    def generate(self, rl_api: RLApi) -> Environment:  # :52-106
+        init = self.draw()
+        env = Environment(self.w, self.h, self.max_steps)
+        perceived = []
+        anthill = Anthill(env, init["anthill_xyr"])
+        perceived.append(anthill)
+        walls = Walls(env)
+        perceived.append(walls)
+        food = Food(env)
+        perceived.append(food)
+        if self.n_rocks > 0:
+            r = init["rocks"]
+            rocks = CircleObstacles(env, r[..., 2][0] if self.n_envs == 1 else r[..., 2],
+                                    r[..., 3][0] if self.n_envs == 1 else r[..., 3])
+            perceived.append(rocks)
+        ants = Ants(env, self.n_ants, self.n_envs, 5)                      # :93
+        perceived.insert(0, ants)                                          # :94
+        for p in range(self.n_pheromones):                                 # :96-99
+            phero = Pheromone(env, p, color=PHERO_COLORS[p % len(PHERO_COLORS)], max_val=255)
+            ants.register_pheromone(phero)
+            perceived.insert(p + 1, phero)
+        rl_api.register_ants(ants)                                         # :101
+        rl_api._pending = (dict(n_envs=self.n_envs, n_ants=self.n_ants, w=self.w, h=self.h,
+                                n_phero=self.n_pheromones, n_rocks=self.n_rocks, max_time=self.max_steps,
+                                max_hold=5.0, phero_max_val=255.0, deposit_strength=1.0), init)
+        mask = None if self.perception_mask is None else np.asarray(self.perception_mask)
+        radius = mask.shape[0] // 2 if mask is not None else 3
+        rl_api.setup_perception(radius, perceived, mask, self.perception_shift)  # :102-105
+        return env

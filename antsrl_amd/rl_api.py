@@ -1,0 +1,452 @@
+"""Host-side mirror of the reference's RLApi / Environment surface.
+
+Same class names, constructor arguments, method names and return tuples as
+environment/RL_api.py, environment/environment.py and the object classes the agents touch,
+so the reference's driver loop (main.py:69-131) and its agents run unchanged:
+
+    api = RLApi(reward=ExplorationReward(), reward_threshold=1, max_speed=1,
+                max_rot_speed=40/180*np.pi, carry_speed_reduction=0.05, backward_speed_reduction=0.5)
+    env = EnvironmentGenerator(w, h, n_ants, 2, 0, food_gen, walls_gen, max_steps, seed).generate(api)
+    obs, agent_state, state = api.observation()
+    obs, agent_state, reward, done = api.step(rotation, pheromone); env.update()
+
+Underneath there is no numpy simulation: every call goes through the C-ABI to the HIP kernels
+(antsrl_amd.batched.BatchedAntsEnv).  The object classes here are *views*: reading
+`pheromone.phero`, `food.qte`, `ants.ants` ... copies that piece of state back from the GPU.
+
+Batching: one RLApi can drive E environments (EnvironmentGenerator(..., n_envs=E)).  With
+E == 1 every array has the reference's shape.  With E > 1 the env axis is folded into the ant
+axis ([E*N, 7, 7, K], n_ants == E*N) so per-ant agents still work unchanged; `done` is then a
+bool array [E].  `as_numpy=False` keeps outputs as torch tensors on the GPU (no PCIe copy).
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import numpy as np
+
+from . import config as cm
+
+AX = np.newaxis  # utils.py:5
+DELTA = 1.1      # environment/RL_api.py:15
+
+
+# ----------------------------------------------------------------------------- world objects
+class EnvObject:  # environment/environment.py:5-18
+    def __init__(self, environment: Optional["Environment"]):
+        self.environment = environment
+        if self.environment is not None:
+            self.environment.add_object(self)
+
+    def visualize_copy(self, newenv):
+        return EnvObject(newenv)
+
+    def update(self):
+        pass
+
+    def update_step(self):
+        return 0
+
+
+class Environment:  # environment/environment.py:21-47
+    def __init__(self, w, h, max_time):
+        self.w, self.h, self.max_time = w, h, max_time
+        self.objects: List[EnvObject] = []
+        self._backend = None
+
+    def add_object(self, obj):
+        self.objects.append(obj)
+
+    def detach_object(self, obj):
+        if obj in self.objects:
+            self.objects.remove(obj)
+
+    @property
+    def timestep(self):
+        if self._backend is None:
+            return 1
+        ts = self._backend.read_state(cm.S_TIMESTEP).cpu().numpy()
+        return int(ts[0]) if ts.size == 1 else ts
+
+    def update(self, wall_jitter=None):
+        """Environment.update (environment.py:42-47): one antsrl_update call.  `wall_jitter`
+        (float64 [E,N]) injects the np.random.random draws of Walls.update (walls.py:28);
+        default is the library's counter-based generator."""
+        self._backend.update(wall_jitter)
+
+    def save_state(self):
+        """Environment.save_state (environment.py:36-40): a host snapshot for the visualiser."""
+        snap = Environment(self.w, self.h, self.max_time)
+        for obj in self.objects:
+            snap.add_object(obj.visualize_copy(snap))
+        return snap
+
+
+class _Snapshot(EnvObject):
+    def __init__(self, env, **kw):
+        super().__init__(None)
+        self.environment = env
+        self.__dict__.update(kw)
+
+
+class _View(EnvObject):
+    """Base of the device-backed object views."""
+
+    def __init__(self, environment, env_index=0):
+        super().__init__(environment)
+        self._e = env_index
+
+    @property
+    def _b(self):
+        return self.environment._backend
+
+    def _read(self, which):
+        return self._b.read_state(which).cpu().numpy()
+
+
+class Pheromone(_View):  # environment/pheromone.py:20-45
+    def __init__(self, environment, index, color=(64, 64, 64), max_val=None):
+        super().__init__(environment)
+        self.index, self.color, self.max_val = index, color, max_val
+        self.w, self.h = environment.w, environment.h
+
+    @property
+    def phero(self):
+        p = self._read(cm.S_PHERO)[:, self.index]
+        return p[0] if p.shape[0] == 1 else p
+
+    def visualize_copy(self, newenv):
+        return _Snapshot(newenv, color=self.color, max_val=self.max_val,
+                         phero=np.asarray(self.phero).astype(np.uint8))  # pheromone.py:17
+
+
+class Food(_View):  # environment/food.py:12-18
+    @property
+    def qte(self):
+        q = self._read(cm.S_FOOD)
+        return q[0] if q.shape[0] == 1 else q
+
+    def visualize_copy(self, newenv):
+        return _Snapshot(newenv, qte=np.asarray(self.qte).astype(np.uint8))  # food.py:10
+
+
+class Walls(_View):  # environment/walls.py:9-30
+    def __init__(self, environment):
+        super().__init__(environment)
+        self.w, self.h = environment.w, environment.h
+        self._map = None
+
+    @property
+    def map(self):
+        if self._map is None:
+            m = self._read(cm.S_WALLS).astype(bool)
+            self._map = m[0] if m.shape[0] == 1 else m
+        return self._map
+
+    def update_step(self):
+        return -1
+
+    def visualize_copy(self, newenv):
+        return self
+
+
+class Anthill(_View):  # environment/anthill.py:16-46
+    def __init__(self, environment, xyr):
+        super().__init__(environment)
+        self.w, self.h = environment.w, environment.h
+        self._xyr = np.asarray(xyr)
+        self._area = None
+
+    @property
+    def x(self):
+        return int(self._xyr[0, 0]) if len(self._xyr) == 1 else self._xyr[:, 0]
+
+    @property
+    def y(self):
+        return int(self._xyr[0, 1]) if len(self._xyr) == 1 else self._xyr[:, 1]
+
+    @property
+    def radius(self):
+        return int(self._xyr[0, 2]) if len(self._xyr) == 1 else self._xyr[:, 2]
+
+    @property
+    def area(self):
+        if self._area is None:
+            a = self._read(cm.S_ANTHILL_AREA).astype(bool)
+            self._area = a[0] if a.shape[0] == 1 else a
+        return self._area
+
+    @property
+    def food(self):
+        f = self._read(cm.S_ANTHILL_FOOD)
+        return float(f[0]) if f.size == 1 else f
+
+    def update_step(self):
+        return 1000
+
+    def visualize_copy(self, newenv):
+        return _Snapshot(newenv, x=self.x, y=self.y, radius=self.radius, food=self.food)
+
+
+class CircleObstacles(_View):  # environment/circle_obstacles.py:15-61
+    def __init__(self, environment, radiuses, weights):
+        super().__init__(environment)
+        self.w, self.h = environment.w, environment.h
+        self.radiuses, self.weights = radiuses, weights
+        self.n_obst = radiuses.shape[-1]
+
+    @property
+    def centers(self):
+        c = self._read(cm.S_ROCK_CENTERS)
+        return c[0] if c.shape[0] == 1 else c
+
+    def visualize_copy(self, newenv):
+        return _Snapshot(newenv, centers=np.array(self.centers), radiuses=np.array(self.radiuses),
+                         weights=np.array(self.weights))
+
+
+class Ants(_View):  # environment/ants.py:17-144
+    def __init__(self, environment, n_ants_per_env, n_envs, max_hold):
+        super().__init__(environment)
+        self._n, self._E = n_ants_per_env, n_envs
+        self.n_ants = n_ants_per_env * n_envs  # the env axis is folded into the ant axis
+        self.max_hold = max_hold
+        self.pheromones: List[Pheromone] = []
+
+    def _flat(self, a):
+        return a.reshape((self.n_ants,) + a.shape[2:])
+
+    @property
+    def ants(self):
+        return self._flat(self._read(cm.S_ANTS_XYT))
+
+    @property
+    def prev_ants(self):
+        return self._flat(self._read(cm.S_PREV_XY))
+
+    @property
+    def x(self):
+        return self.ants[:, 0]
+
+    @property
+    def y(self):
+        return self.ants[:, 1]
+
+    @property
+    def xy(self):
+        return self.ants[:, 0:2]
+
+    @property
+    def theta(self):
+        return self.ants[:, 2]
+
+    @property
+    def holding(self):
+        return self._flat(self._read(cm.S_HOLDING))
+
+    @property
+    def mandibles(self):
+        return self._flat(self._read(cm.S_MANDIBLES)).astype(bool)
+
+    @property
+    def seed(self):
+        return self._flat(self._read(cm.S_SEED))
+
+    @property
+    def reward_state(self):
+        return self._flat(self._read(cm.S_REWARD_STATE))
+
+    @property
+    def phero_activation(self):
+        return self._flat(self._read(cm.S_ACTIVATION))
+
+    def register_pheromone(self, pheromone):  # ants.py:82-84
+        self.pheromones.append(pheromone)
+
+    def activate_all_pheromones(self, new_activations):
+        """ants.py:86-87.  The reference's activation matrix is bool until this call replaces it
+        with a float array; from then on activate_pheromone's 256 deposits 256.0 instead of
+        True == 1.0.  A float argument therefore also switches the deposit
+        strength to 256."""
+        a = np.asarray(new_activations)
+        strength = 0.0 if a.dtype == np.bool_ else 256.0
+        self._b.set_activation(a.astype(np.float32).reshape(self._E, self._n, -1), strength)
+
+    def update_step(self):
+        return 999
+
+    def visualize_copy(self, newenv):
+        return _Snapshot(newenv, ants=self.ants, mandibles=self.mandibles, holding=self.holding,
+                         reward_state=self.reward_state)
+
+
+# ----------------------------------------------------------------------------- rewards
+class Reward:  # environment/rewards/reward.py:6-45
+    kind = cm.REWARD_NONE
+
+    def __init__(self):
+        self.ants = None
+        self.environment = None
+        self.rewards = None
+
+    def setup(self, ants):
+        self.ants = ants
+        self.environment = ants.environment
+        self.rewards = np.zeros(ants.n_ants, dtype=float)
+
+    def weights(self):
+        return {}
+
+    def visualization(self):
+        return None
+
+
+class _ExploredMixin:
+    @property
+    def explored_map(self):
+        m = self.environment._backend.read_state(cm.S_EXPLORED).cpu().numpy().astype(bool)
+        return m[0] if m.shape[0] == 1 else m
+
+    def visualization(self):
+        return self.explored_map.copy()
+
+
+class ExplorationReward(_ExploredMixin, Reward):  # reward_custom.py:8-25
+    kind = cm.REWARD_EXPLORATION
+
+
+class Food_Reward(Reward):  # reward_custom.py:28-40
+    kind = cm.REWARD_FOOD
+
+
+class All_Rewards(_ExploredMixin, Reward):  # reward_custom.py:43-109
+    kind = cm.REWARD_ALL
+
+    def __init__(self, fct_explore=1, fct_food=1, fct_anthill=5, fct_explore_holding=0, fct_headinganthill=1):
+        super().__init__()
+        self.fct_explore, self.fct_food, self.fct_anthill = fct_explore, fct_food, fct_anthill
+        self.fct_explore_holding, self.fct_headinganthill = fct_explore_holding, fct_headinganthill
+
+    def weights(self):
+        return dict(fct_explore=float(self.fct_explore), fct_food=float(self.fct_food),
+                    fct_anthill=float(self.fct_anthill), fct_explore_holding=float(self.fct_explore_holding),
+                    fct_headinganthill=float(self.fct_headinganthill))
+
+
+# ----------------------------------------------------------------------------- RLApi
+_KIND_OF = {Ants: cm.CH_ANTS, Pheromone: cm.CH_PHERO, Anthill: cm.CH_ANTHILL, Walls: cm.CH_WALLS,
+            Food: cm.CH_FOOD, CircleObstacles: cm.CH_ROCKS}
+
+
+class RLApi(EnvObject):  # environment/RL_api.py:22-204
+    def __init__(self, reward: Reward, reward_threshold: float, max_speed: float, max_rot_speed: float,
+                 carry_speed_reduction: float, backward_speed_reduction: float, as_numpy: bool = True):
+        super().__init__(None)
+        self.reward = reward
+        self.reward_threshold = reward_threshold
+        self.ants: Optional[Ants] = None
+        self.original_ants_position = None
+        self.perception_radius = 0
+        self.perception_mask = None
+        self.perceived_objects: List[EnvObject] = []
+        self.perception_coords = None
+        self.perception_fwd_delta = 0
+        self.max_speed, self.max_rot_speed = max_speed, max_rot_speed
+        self.carry_speed_reduction = carry_speed_reduction
+        self.backward_speed_reduction = backward_speed_reduction
+        self.save_perceptive_field = False  # GUI only (RL_api.py:49,144-153): accepted, not produced
+        self.perceptive_field = None
+        self.as_numpy = as_numpy
+        self._pending = None  # (base cfg kwargs, init arrays) from the generator
+        self._backend = None
+
+    # -- wiring ----------------------------------------------------------------
+    def register_ants(self, new_ants: Ants):  # RL_api.py:57-66
+        if self.environment is not None:
+            self.environment.detach_object(self)
+        self.ants = new_ants
+        self.environment = new_ants.environment
+        self.environment.add_object(self)
+        self.perceived_objects = []
+        self.reward.setup(self.ants)
+
+    def setup_perception(self, radius: int, objects: List[EnvObject], mask=None, forward_delta=0):
+        """RL_api.py:80-93.  (Re)creates the device batch for this perception set-up and loads the
+        generator's initial state into it, so it must precede the first observation()/step()."""
+        self.perception_radius = radius
+        self.perception_mask = mask
+        self.perceived_objects = objects
+        self.perception_fwd_delta = forward_delta
+        rng = np.arange(-radius, radius + 1)
+        self.perception_coords = np.dstack([rng[AX, :].repeat(2 * radius + 1, 0),
+                                            rng[:, AX].repeat(2 * radius + 1, 1)]).astype(float) * DELTA
+        if self._pending is not None:
+            self._materialize()
+
+    def _channels(self):
+        ch = []
+        for obj in self.perceived_objects:
+            kind = next((k for cls, k in _KIND_OF.items() if isinstance(obj, cls)), None)
+            if kind is None:
+                raise TypeError("cannot perceive %r" % (obj,))
+            ch.append((kind, obj.index if kind == cm.CH_PHERO else 0))
+        return ch
+
+    def _materialize(self):
+        from .batched import BatchedAntsEnv
+        kw, init = self._pending
+        cfg = cm.make_cfg(mask=self.perception_mask, perception_radius=self.perception_radius,
+                          fwd_delta=float(self.perception_fwd_delta), delta=DELTA, channels=self._channels(),
+                          max_speed=float(self.max_speed), max_rot_speed=float(self.max_rot_speed),
+                          carry_speed_reduction=float(self.carry_speed_reduction),
+                          backward_speed_reduction=float(self.backward_speed_reduction),
+                          reward_kind=self.reward.kind, reward_threshold=float(self.reward_threshold),
+                          **self.reward.weights(), **kw)
+        self._backend = BatchedAntsEnv(cfg)
+        self._backend.reset(init)
+        self.environment._backend = self._backend
+
+    # -- outputs ---------------------------------------------------------------
+    def _out(self, t, fold=True):
+        if fold:
+            t = t.reshape((t.shape[0] * t.shape[1],) + tuple(t.shape[2:]))
+        return t.cpu().numpy() if self.as_numpy else t
+
+    def _acts(self, a):
+        if a is None:
+            return None
+        c = self._backend.cfg
+        if hasattr(a, "detach"):
+            return a.reshape(c.n_envs, c.n_ants)
+        return np.asarray(a).reshape(c.n_envs, c.n_ants)
+
+    def observation(self):
+        """RL_api.py:96-165 -> (perception [n,P,P,K], agent_state [n,2], state [n,2+C])."""
+        b = self._backend
+        obs, ast, rew = b.observe()
+        self.reward.rewards = self._out(rew)
+        state = self._state()
+        return self._out(obs), self._out(ast), state
+
+    def _state(self):  # RL_api.py:155-158
+        import torch
+        b = self._backend
+        m = b.read_state(cm.S_MANDIBLES).to(torch.float32)
+        h = b.read_state(cm.S_HOLDING)
+        a = (b.read_state(cm.S_ACTIVATION) > 0).to(torch.float32)
+        return self._out(torch.cat([m[..., None], h[..., None], a], dim=-1))
+
+    def step(self, rotation, on_off_pheromones):
+        """RL_api.py:168-204 -> (perception, agent_state, reward, done)."""
+        b = self._backend
+        obs, ast, rew, done = b.step(self._acts(rotation), self._acts(on_off_pheromones))
+        r = self._out(rew)
+        self.reward.rewards = r
+        if b.cfg.n_envs == 1:
+            d = bool(done.cpu().numpy()[0])
+        else:
+            d = done.cpu().numpy().astype(bool) if self.as_numpy else done
+        return self._out(obs), self._out(ast), r, d
+
+    def visualize_copy(self, newenv):
+        return _Snapshot(newenv, heatmap=self.reward.visualization())

@@ -159,15 +159,15 @@ def main():
     g.manual_seed(99 + rank)
     rot = torch.randint(-1, 2, (RING, E, cfg.n_ants), generator=g, device=dev, dtype=torch.int8)
     ph = torch.randint(0, 3, (RING, E, cfg.n_ants), generator=g, device=dev, dtype=torch.int8)
+    gather = None
     if world > 1:
-        rew_all = torch.empty((world * E, cfg.n_ants), dtype=torch.float32, device=dev)
-        done_all = torch.empty((world * E,), dtype=torch.uint8, device=dev)
+        from antsrl_amd.dist import RewardGather
+        gather = RewardGather(world * E, cfg.n_ants, dev)
 
     def one_step(t):
         env.step_update(rot[t % RING], ph[t % RING], None)
-        if world > 1:  # the path's only exchange: reward/done all-gather
-            dist.all_gather_into_tensor(rew_all, env.reward)
-            dist.all_gather_into_tensor(done_all, env.done)
+        if gather is not None:  # the path's only exchange: reward/done all-gather
+            gather(env.reward, env.done)
 
     for t in range(args.warmup):
         one_step(t)

@@ -1,0 +1,75 @@
+"""N > 1 path on CPU: world_size-2 (and 3, ragged) gloo processes shard the env batch and
+all-gather reward/done exactly as bench.py / a multi-GPU driver does over RCCL."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from antsrl_amd.config import make_cfg
+from antsrl_amd.dist import RewardGather, shard_range
+from antsrl_amd.synth import synth_init
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, E, N, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        lo, hi = shard_range(E, rank, world)
+        # each rank draws ITS block of the global batch: same arrays as the single-process batch
+        cfg = make_cfg(hi - lo, N, 32, 32)
+        init = synth_init(cfg, seed=50, env_offset=lo, n_food_discs=3, food_rmin=2, food_rmax=4)
+        g = RewardGather(E, N, "cpu")
+        out = []
+        for step in range(3):
+            rew = torch.full((hi - lo, N), float(step)) + torch.arange(lo, hi, dtype=torch.float32)[:, None]
+            done = torch.tensor([(e + step) % 2 for e in range(lo, hi)], dtype=torch.uint8)
+            r, d = g(rew, done)
+            out.append((r.clone().numpy(), d.clone().numpy()))
+        q.put((rank, init["ants_xyt"], out))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,E", [(2, 8), (3, 7)])
+def test_sharded_envs_and_reward_gather(world, E):
+    N = 5
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, E, N, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    full = synth_init(make_cfg(E, N, 32, 32), seed=50, n_food_discs=3, food_rmin=2, food_rmax=4)["ants_xyt"]
+    np.testing.assert_array_equal(np.concatenate([r[1] for r in res]), full)  # shards tile the batch
+    for step in range(3):
+        want_r = np.full((E, N), float(step)) + np.arange(E, dtype=np.float32)[:, None]
+        want_d = np.array([(e + step) % 2 for e in range(E)], np.uint8)
+        for _, _, out in res:  # every rank sees the whole batch
+            np.testing.assert_array_equal(out[step][0], want_r)
+            np.testing.assert_array_equal(out[step][1], want_d)
+
+
+def test_shard_range_partitions():
+    for E in (1, 7, 8, 1024, 8192):
+        for world in (1, 2, 3, 8):
+            r = [shard_range(E, k, world) for k in range(world)]
+            assert r[0][0] == 0 and r[-1][1] == E
+            assert all(r[k][1] == r[k + 1][0] for k in range(world - 1))
+            assert max(h - l for l, h in r) - min(h - l for l, h in r) <= 1

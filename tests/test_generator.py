@@ -1,0 +1,88 @@
+"""Host logic: the episode generator draws the same initial state as the reference's
+EnvironmentGenerator.generate for the same seed (compared with the initial arrays recorded in
+the golden fixtures), and the reference-path import aliases resolve.  CPU only."""
+import json
+import random
+
+import numpy as np
+import pytest
+
+from helpers import fixture_names, load_fixture
+from antsrl_amd.generator import CirclesGenerator, EnvironmentGenerator
+
+
+class BernoulliWalls:  # same stand-in as tests/golden/make_golden.py
+    def __init__(self, density, rng):
+        self.density, self.rng = density, rng
+
+    def generate(self, w, h):
+        return self.rng.random((w, h)) < self.density
+
+
+class FoodNearAnthill:  # same stand-in as tests/golden/make_golden.py
+    def __init__(self, n, rmin, rmax, extra=None, rich=None):
+        self.base, self.extra, self.rich = CirclesGenerator(n, rmin, rmax), extra, rich
+
+    def generate(self, w, h):
+        g = self.base.generate(w, h)
+        if self.extra is not None:
+            cx, cy, r = self.extra
+            xs, ys = np.meshgrid(np.arange(w), np.arange(h), indexing="ij")
+            g |= ((xs - cx) ** 2 + (ys - cy) ** 2) <= r * r
+        if self.rich is not None:
+            return g.astype(int) * self.rich.integers(1, 9, size=g.shape)
+        return g
+
+
+WALL_DENSITY = {"s01_plain": 0.0, "s06_food_reward": 0.03, "s13_rich_food": 0.03}
+
+
+@pytest.mark.parametrize("name", fixture_names())
+def test_generator_draws_reference_initial_state(name):
+    cfg, init, F, meta = load_fixture(name)
+    seed, w, h = meta["seed"], meta["w"], meta["h"]
+    rng = np.random.default_rng(1000 + seed)
+    random.seed(seed)
+    ax = int(random.random() * w * 0.5 + w * 0.25)
+    ay = int(random.random() * h * 0.5 + h * 0.25)
+    food_gen = FoodNearAnthill(6, 3, 6, (ax + 2, ay + 1, 6), rng if name == "s13_rich_food" else None)
+    gen = EnvironmentGenerator(w, h, meta["n_ants"], meta["n_phero"], 0, food_gen,
+                               BernoulliWalls(WALL_DENSITY.get(name, 0.05), rng), meta["max_time"], seed=seed)
+    d = gen.draw()
+    np.testing.assert_array_equal(d["ants_xyt"][0], F["init_ants_xyt"])
+    np.testing.assert_array_equal(d["seed"][0], F["init_seed"])
+    np.testing.assert_array_equal(d["walls"][0], F["init_walls"].astype(np.uint8))
+    np.testing.assert_array_equal(d["food"][0], F["init_food"].astype(np.float32))
+    np.testing.assert_array_equal(d["anthill_xyr"][0], F["init_anthill_xyr"])
+
+
+def test_batch_uses_consecutive_seeds():
+    g1 = EnvironmentGenerator(32, 32, 8, 2, 2, CirclesGenerator(3, 2, 4), BernoulliWalls(0.1, np.random.default_rng(0)),
+                              100, seed=5, n_envs=3)
+    d = g1.draw()
+    assert d["ants_xyt"].shape == (3, 8, 3) and d["rocks"].shape == (3, 2, 4)
+    g2 = EnvironmentGenerator(32, 32, 8, 2, 2, CirclesGenerator(3, 2, 4), BernoulliWalls(0.1, np.random.default_rng(0)),
+                              100, seed=6, n_envs=1)
+    np.testing.assert_array_equal(g2.draw()["ants_xyt"][0], d["ants_xyt"][1])
+    # rocks follow the reference's intended placement band (environment_generator.py:77-81)
+    assert (d["rocks"][..., 0] >= 8).all() and (d["rocks"][..., 1] >= 8).all() and (d["rocks"][..., 1] <= 16).all()
+
+
+def test_reference_import_aliases():
+    import sys
+    from antsrl_amd import compat, rl_api
+    saved = {k: v for k, v in sys.modules.items() if k.split(".")[0] in ("environment", "generator")}
+    try:
+        for k in saved:
+            del sys.modules[k]
+        compat.install_reference_aliases()
+        from environment.RL_api import RLApi
+        from environment.pheromone import Pheromone
+        from environment.rewards.reward_custom import All_Rewards
+        from generator.environment_generator import EnvironmentGenerator as EG
+        assert RLApi is rl_api.RLApi and Pheromone is rl_api.Pheromone and EG is EnvironmentGenerator
+        assert All_Rewards(fct_food=2).weights()["fct_food"] == 2.0
+    finally:
+        for k in [k for k in sys.modules if k.split(".")[0] in ("environment", "generator")]:
+            del sys.modules[k]
+        sys.modules.update(saved)

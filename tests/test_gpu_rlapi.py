@@ -1,0 +1,91 @@
+"""The reference-shaped Python surface (antsrl_amd.RLApi / EnvironmentGenerator / views) driven
+exactly like main.py:69-131 and compared with the reference's golden run of the same seed."""
+import random
+
+import numpy as np
+import pytest
+
+from helpers import OP_STEP, OP_UPDATE, load_fixture, phero_close
+from test_generator import BernoulliWalls, FoodNearAnthill, WALL_DENSITY
+
+pytestmark = pytest.mark.gpu
+
+
+def build(name, as_numpy=True):
+    from antsrl_amd.generator import EnvironmentGenerator
+    from antsrl_amd.rl_api import All_Rewards, ExplorationReward, Food_Reward, Reward, RLApi
+    cfg, init, F, meta = load_fixture(name)
+    seed, w, h = meta["seed"], meta["w"], meta["h"]
+    rng = np.random.default_rng(1000 + seed)
+    random.seed(seed)
+    ax = int(random.random() * w * 0.5 + w * 0.25)
+    ay = int(random.random() * h * 0.5 + h * 0.25)
+    reward = {"exploration": ExplorationReward, "food": Food_Reward, "none": Reward}.get(meta["reward"])
+    reward = All_Rewards(**meta["weights"]) if meta["reward"] == "all" else reward()
+    api = RLApi(reward=reward, reward_threshold=1, max_speed=1, max_rot_speed=40 / 180 * np.pi,
+                carry_speed_reduction=0.05, backward_speed_reduction=0.5, as_numpy=as_numpy)
+    gen = EnvironmentGenerator(w, h, meta["n_ants"], meta["n_phero"], 0,
+                               FoodNearAnthill(6, 3, 6, (ax + 2, ay + 1, 6)),
+                               BernoulliWalls(WALL_DENSITY.get(name, 0.05), rng), meta["max_time"], seed=seed)
+    env = gen.generate(api)
+    return api, env, F, meta
+
+
+@pytest.mark.parametrize("name", ["s02_walls", "s05_all_rewards", "s06_food_reward"])
+def test_rlapi_shim_replays_reference_run(name):
+    from antsrl_amd.rl_api import Pheromone
+    api, env, F, meta = build(name)
+    # what agents read (agents/agent.py:22-25, collect_agent_memory.py:129-131)
+    assert api.perception_coords.shape[:2] == (7, 7) and len(api.perceived_objects) == 6
+    assert api.ants.n_ants == meta["n_ants"]
+    n_ph = sum(isinstance(o, Pheromone) for o in api.perceived_objects)
+    assert n_ph == 2
+    if meta["deposit_strength"] != 1.0:
+        api.ants.activate_all_pheromones(np.ones((api.ants.n_ants, n_ph)) * 10)
+    for t, op in enumerate(F["ops"]):
+        if op == OP_STEP:
+            obs, ast, rew, done = api.step(F["rot"][t], F["ph"][t])
+            assert obs.shape == F["obs"][t].shape and isinstance(done, bool) and done == bool(F["done"][t])
+            np.testing.assert_array_equal(rew, F["reward"][t].astype(np.float32))
+            np.testing.assert_array_equal(ast, F["agent_state"][t].astype(np.float32))
+            ints = [k for k in range(6) if k not in (1, 2)]
+            np.testing.assert_array_equal(obs[..., ints], F["obs"][t][..., ints])
+            assert np.abs(obs[..., 1:3] - F["obs"][t][..., 1:3]).max() < 2e-5
+        elif op == OP_UPDATE:
+            env.update(F["jitter"][t][None])
+            assert env.timestep == F["timestep"][t]
+    np.testing.assert_allclose(api.ants.ants, F["ants"][-1], rtol=0, atol=1e-9)
+    np.testing.assert_array_equal(api.ants.holding, F["holding"][-1])
+    food = [o for o in env.objects if type(o).__name__ == "Food"][0]
+    np.testing.assert_array_equal(food.qte, F["food"][-1])
+    anthill = [o for o in env.objects if type(o).__name__ == "Anthill"][0]
+    assert anthill.food == F["anthill_food"][-1]
+    for c, p in enumerate(api.ants.pheromones):
+        assert phero_close(p.phero, F["phero"][-1][c]).all()
+    if meta["reward"] in ("exploration", "all"):
+        np.testing.assert_array_equal(api.reward.explored_map, F["explored"][-1].astype(bool))
+    snap = env.save_state()  # Environment.save_state, environment.py:36-40
+    assert len(snap.objects) == len(env.objects)
+
+
+def test_rlapi_initial_observation_and_state():
+    api, env, F, meta = build("s02_walls")
+    obs, ast, state = api.observation()  # main.py:88
+    assert obs.shape == (32, 7, 7, 6) and ast.shape == (32, 2) and state.shape == (32, 4)
+    assert (state[:, 0] == 0).all() and (state[:, 2:] == 0).all()
+
+
+def test_rlapi_batched_fold_and_device_tensors():
+    """n_envs > 1: env axis folded into the ant axis; as_numpy=False keeps torch tensors on the GPU."""
+    import torch
+    from antsrl_amd.generator import BernoulliGenerator, CirclesGenerator, EnvironmentGenerator
+    from antsrl_amd.rl_api import ExplorationReward, RLApi
+    api = RLApi(ExplorationReward(), 1, 1, 40 / 180 * np.pi, 0.05, 0.5, as_numpy=False)
+    env = EnvironmentGenerator(64, 64, 16, 2, 3, CirclesGenerator(5, 3, 6), BernoulliGenerator(0.05), 50,
+                               seed=7, n_envs=4).generate(api)
+    assert api.ants.n_ants == 64 and len(api.perceived_objects) == 7
+    rot = torch.randint(-1, 2, (64,), dtype=torch.int8, device="cuda")
+    obs, ast, rew, done = api.step(rot, None)
+    assert obs.is_cuda and obs.shape == (64, 7, 7, 7) and rew.shape == (64,) and done.shape == (4,)
+    env.update()
+    assert (env.timestep == 2).all()
