@@ -28,6 +28,7 @@ MAX_PHERO = 4
 
 CH_ANTS, CH_PHERO, CH_ANTHILL, CH_WALLS, CH_FOOD, CH_ROCKS = range(6)
 REWARD_NONE, REWARD_EXPLORATION, REWARD_FOOD, REWARD_ALL = range(4)
+PHERO_AUTO, PHERO_EXPLICIT_SWEEP = 0, 1
 
 (S_ANTS_XYT, S_PREV_XY, S_HOLDING, S_MANDIBLES, S_ACTIVATION, S_PHERO, S_FOOD, S_EXPLORED,
  S_ANTHILL_FOOD, S_ROCK_CENTERS, S_TIMESTEP, S_REWARD_STATE, S_WALLS, S_ANTHILL_AREA,
@@ -65,7 +66,7 @@ class AntsCfg(C.Structure):
         ("phero_threshold", C.c_double),
         ("filter", C.c_double * MAX_FILTER_TAPS),
         ("reward_kind", C.c_int32),
-        ("_pad1", C.c_int32),
+        ("phero_mode", C.c_int32),
         ("reward_threshold", C.c_double),
         ("fct_explore", C.c_double),
         ("fct_food", C.c_double),
@@ -140,7 +141,8 @@ def make_cfg(n_envs: int, n_ants: int, w: int, h: int, *, n_phero: int = 2, n_ro
              filt: Optional[np.ndarray] = None, reward_kind: int = REWARD_EXPLORATION,
              reward_threshold: float = 1.0, fct_explore: float = 1.0, fct_food: float = 1.0,
              fct_anthill: float = 5.0, fct_explore_holding: float = 0.0,
-             fct_headinganthill: float = 1.0, rng_seed: int = 0x5EED) -> AntsCfg:
+             fct_headinganthill: float = 1.0, rng_seed: int = 0x5EED,
+             phero_mode: int = PHERO_AUTO) -> AntsCfg:
     """Build an AntsCfg with the reference's defaults (see module docstring)."""
     c = AntsCfg()
     c.abi_version = ABI_VERSION
@@ -199,6 +201,7 @@ def make_cfg(n_envs: int, n_ants: int, w: int, h: int, *, n_phero: int = 2, n_ro
     c.fct_explore, c.fct_food, c.fct_anthill = fct_explore, fct_food, fct_anthill
     c.fct_explore_holding, c.fct_headinganthill = fct_explore_holding, fct_headinganthill
     c.rng_seed = rng_seed
+    c.phero_mode = phero_mode
     return c
 
 
@@ -212,3 +215,10 @@ def mask_array(cfg: AntsCfg) -> Optional[np.ndarray]:
 __all__ = [n for n in dir() if n.isupper() or n in (
     "AntsCfg", "AntsInit", "make_cfg", "diffuse_filter", "default_channels", "mask_array")]
 _ = math
+
+
+def uses_scaled_units(cfg: AntsCfg) -> bool:
+    """Mirror of use_scaled() in csrc/antsrl_capi.hip: a centre-only decay filter under
+    PHERO_AUTO is held in units of f0^S and needs no per-step sweep."""
+    return (cfg.phero_mode == PHERO_AUTO and cfg.filter_radius == 0 and 0.5 < cfg.filter[0] <= 1.0
+            and cfg.phero_threshold >= 0.0)

@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <math.h>
 #include <string.h>
 #include <new>
 
@@ -21,6 +22,8 @@ hipError_t antsrl_launch_collect_full(const KP &p, hipStream_t st);
 hipError_t antsrl_launch_reset(const KP &p, const AntsInit *in, hipStream_t st);
 hipError_t antsrl_launch_set_activation(const KP &p, const float *act, hipStream_t st);
 hipError_t antsrl_launch_read_state(const KP &p, int which, int cur, void *dst, hipStream_t st);
+hipError_t antsrl_launch_phero_wall_clear(const KP &p, hipStream_t st);
+hipError_t antsrl_launch_phero_renorm(const KP &p, hipStream_t st);
 
 struct AntsHandle {
     AntsCfg cfg;
@@ -30,6 +33,8 @@ struct AntsHandle {
     bool need_full_collect;// next update must run Anthill.update over the whole grid
     bool is_reset;
     size_t ws_bytes;
+    long long sweeps;      // scaled mode: updates since the units were last re-based
+    bool need_wall_clear;  // scaled mode: initial grid may hold pheromone on wall cells
     hipEvent_t ev[4];      // measurement hook (antsrl_set_timing_events)
     bool ev_armed;
 };
@@ -74,6 +79,8 @@ static int validate(const AntsCfg *c)
         if (kind < ANTSRL_CH_ANTS || kind > ANTSRL_CH_ROCKS) return fail(ANTSRL_E_INVALID, "bad channel kind");
         if (kind == ANTSRL_CH_PHERO && (c->channel_arg[k] < 0 || c->channel_arg[k] >= c->n_phero))
             return fail(ANTSRL_E_INVALID, "pheromone channel index out of range");
+        if (kind == ANTSRL_CH_PHERO && !c->has_max_val) // phero / None raises TypeError, RL_api.py:125
+            return fail(ANTSRL_E_INVALID, "a perceived pheromone needs max_val (RL_api.py:125 divides by it)");
         if (kind == ANTSRL_CH_ROCKS && c->n_rocks == 0)
             return fail(ANTSRL_E_INVALID, "rocks perceived but n_rocks == 0");
     }
@@ -83,6 +90,14 @@ static int validate(const AntsCfg *c)
         return fail(ANTSRL_E_INVALID, "bad reward_kind");
     if (c->has_max_val && !(c->phero_max_val > 0)) return fail(ANTSRL_E_INVALID, "phero_max_val must be > 0");
     return ANTSRL_OK;
+}
+
+// Scaled pheromone units (see ANTSRL_PHERO_AUTO in antsrl.h) apply to a centre-only filter whose
+// coefficient is a genuine decay; anything else takes the explicit sweep.
+static bool use_scaled(const AntsCfg *c)
+{
+    return c->phero_mode == ANTSRL_PHERO_AUTO && c->filter_radius == 0 && c->filter[0] > 0.5 &&
+           c->filter[0] <= 1.0 && c->phero_threshold >= 0.0;
 }
 
 // Carves the workspace; with base == NULL only computes the size.
@@ -105,7 +120,9 @@ static size_t carve(const AntsCfg *c, DState *s, unsigned char *base)
     d.activation = (float *)take(4 * E * N * Cn);
     d.mandibles = (uint8_t *)take(E * N); d.reward_state = (uint8_t *)take(E * N);
     d.dirty_cell = (int32_t *)take(4 * E * N);
-    d.phero[0] = (float *)take(4 * E * G * Cn); d.phero[1] = (float *)take(4 * E * G * Cn);
+    d.walldep_cell = (int32_t *)take(4 * E * N);
+    d.phero[0] = (float *)take(4 * E * G * Cn);
+    d.phero[1] = use_scaled(c) ? d.phero[0] : (float *)take(4 * E * G * Cn); // no ping-pong when scaled
     d.food = (float *)take(4 * E * G);
     d.walls_bits = (uint32_t *)take(4 * E * words); d.area_bits = (uint32_t *)take(4 * E * words);
     d.explored_bits = (uint32_t *)take(4 * E * words);
@@ -147,6 +164,18 @@ static void fill_kp(const AntsCfg *c, KP *p)
     p->fct_explore_holding = c->fct_explore_holding; p->fct_heading = c->fct_headinganthill;
     memcpy(p->filter, c->filter, sizeof(p->filter));
     p->rng_seed = c->rng_seed;
+    p->scaled = use_scaled(c) ? 1 : 0;
+    p->g_now = p->g_dep = p->inv_g_dep = 1.0;
+}
+
+// f0^S for the next observation, f0^(S+1) for the next deposit
+static void set_decay(AntsHandle *h)
+{
+    if (!h->p.scaled) return;
+    const double f0 = h->cfg.filter[0];
+    h->p.g_now = pow(f0, (double)h->sweeps);
+    h->p.g_dep = pow(f0, (double)(h->sweeps + 1));
+    h->p.inv_g_dep = 1.0 / h->p.g_dep;
 }
 
 extern "C" int antsrl_workspace_bytes(const AntsCfg *cfg, size_t *bytes)
@@ -174,6 +203,7 @@ extern "C" int antsrl_create(const AntsCfg *cfg, void *workspace, size_t workspa
     fill_kp(cfg, &h->p);
     carve(cfg, &h->p.s, (unsigned char *)workspace);
     h->cur = 0; h->steps_since_update = 0; h->need_full_collect = true; h->is_reset = false;
+    h->sweeps = 0; h->need_wall_clear = false;
     h->ws_bytes = need;
     h->ev_armed = false;
     if (!antsrl_act_fits(h->p)) {
@@ -198,6 +228,8 @@ extern "C" int antsrl_reset(AntsHandle *h, const AntsInit *init, void *stream)
     if (e != hipSuccess) return hip_fail(e, "reset");
     h->p.deposit_strength = h->cfg.deposit_strength;
     h->cur = 0; h->steps_since_update = 0; h->need_full_collect = true; h->is_reset = true;
+    h->sweeps = 0; h->need_wall_clear = h->p.scaled && init->phero != nullptr;
+    set_decay(h);
     return ANTSRL_OK;
 }
 
@@ -219,18 +251,35 @@ static int do_step(AntsHandle *h, const int8_t *rot, const int8_t *ph, float *ob
 static int do_update(AntsHandle *h, const double *jitter, hipStream_t st, bool sweep_done)
 {
     hipError_t e;
-    if (!sweep_done) {
+    if (h->p.scaled) {
+        if (h->p.g_dep < 1e-20) { // re-base the units long before u = v / f0^S can overflow fp32
+            e = antsrl_launch_phero_renorm(h->p, st);
+            if (e != hipSuccess) return hip_fail(e, "pheromone renorm");
+            h->sweeps = 0;
+            set_decay(h);
+        }
+        if (h->need_wall_clear) { // Walls pass of this update (walls.py:30) on the initial grid,
+                                  // before this update's deposits land
+            e = antsrl_launch_phero_wall_clear(h->p, st);
+            if (e != hipSuccess) return hip_fail(e, "pheromone wall clear");
+            h->need_wall_clear = false;
+        }
+    } else if (!sweep_done) {
         e = antsrl_launch_sweep(h->p, h->cur, st);
         if (e != hipSuccess) return hip_fail(e, "pheromone sweep");
     }
-    e = antsrl_launch_update(h->p, jitter, h->cur ^ 1, st);
+    e = antsrl_launch_update(h->p, jitter, h->p.scaled ? 0 : h->cur ^ 1, st);
     if (e != hipSuccess) return hip_fail(e, "update");
+    if (h->p.scaled) {
+        h->sweeps++;
+        set_decay(h);
+    }
     if (h->need_full_collect) {
         e = antsrl_launch_collect_full(h->p, st);
         if (e != hipSuccess) return hip_fail(e, "anthill collect");
         h->need_full_collect = false;
     }
-    h->cur ^= 1;
+    if (!h->p.scaled) h->cur ^= 1;
     h->steps_since_update = 0;
     return ANTSRL_OK;
 }
@@ -274,8 +323,10 @@ extern "C" int antsrl_step_update(AntsHandle *h, const int8_t *rotation, const i
     if (timed) (void)hipEventRecord(h->ev[0], st);
     // The sweep only reads phero[cur] and the wall bitmap, so it can be enqueued first: the
     // perception gather of the step reads the same (pre-update) buffer.
-    hipError_t e = antsrl_launch_sweep(h->p, h->cur, st);
-    if (e != hipSuccess) return hip_fail(e, "pheromone sweep");
+    if (!h->p.scaled) {
+        hipError_t e = antsrl_launch_sweep(h->p, h->cur, st);
+        if (e != hipSuccess) return hip_fail(e, "pheromone sweep");
+    }
     if (timed) (void)hipEventRecord(h->ev[1], st);
     int rc = do_step(h, rotation, phero, obs, agent_state, reward, done, st);
     if (rc) return rc;

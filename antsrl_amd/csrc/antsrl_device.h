@@ -23,6 +23,8 @@ struct DState {
     uint8_t *mandibles, *reward_state;       // [E*N]
     int32_t *dirty_cell;                     // [E*N]  food cell on the anthill area this ant
                                              //        rewrote in the last step, else -1
+    int32_t *walldep_cell;                   // [E*N]  (scaled mode) wall cell this ant deposited
+                                             //        on in the last update, else -1
     float *phero[2];                         // [E*G*C] each
     float *food;                             // [E*G]
     uint32_t *walls_bits, *area_bits, *explored_bits; // [E*words]
@@ -47,6 +49,12 @@ struct KP {
     double fct_explore, fct_food, fct_anthill, fct_explore_holding, fct_heading;
     double filter[ANTSRL_MAX_FILTER_TAPS];
     uint64_t rng_seed;
+    // Scaled pheromone representation (ANTSRL_PHERO_AUTO with a centre-only filter): the grid
+    // holds u = v / f0^S_at_write; v_now = u * g_now with g = f0^S.  g == 1 in explicit mode.
+    int32_t scaled, _pad;
+    double g_now;     // f0^S          : materialises values for the perception gather / read-out
+    double g_dep;     // f0^(S+1)      : at deposit time, after the conceptual sweep of this update
+    double inv_g_dep; // 1 / g_dep
 };
 
 // k_act flags

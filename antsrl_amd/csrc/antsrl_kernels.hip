@@ -335,6 +335,8 @@ k_act(const KP p, const int8_t *__restrict__ rotation, const int8_t *__restrict_
     float *obs_env = (flags & ACT_HAS_OBS) ? obs + (size_t)e * total * K : nullptr;
     const bool vec_ok = (((size_t)total * K) % 4 == 0);
     const float inv_max = 1.0f / (float)p.max_val;
+    const float g_now = (float)p.g_now;                       // scaled mode: v = u * f0^S ...
+    const float cut = p.scaled ? (float)p.threshold : 0.0f;   // ... and 0 below the 0.01 cut
     for (uint32_t base = (uint32_t)wave * ACT_ITEMS; base < total; base += (uint32_t)nwaves * ACT_ITEMS) {
         uint32_t ant[ACT_UNROLL], cell[ACT_UNROLL];
         int ixv[ACT_UNROLL], iyv[ACT_UNROLL];
@@ -373,6 +375,15 @@ k_act(const KP p, const int8_t *__restrict__ rotation, const int8_t *__restrict_
                 }
                 fd[u] = food[cell[u]];
             }
+        }
+        if (p.scaled) {
+#pragma unroll
+            for (int u = 0; u < ACT_UNROLL; ++u)
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    const float v = pv[u][c] * g_now;
+                    pv[u][c] = v < cut ? 0.0f : v;
+                }
         }
 #pragma unroll
         for (int u = 0; u < ACT_UNROLL; ++u) {
@@ -637,17 +648,52 @@ k_update(const KP p, const double *__restrict__ wall_jitter, const int out_buf)
         p.s.reward_state[eN + i] = (uint8_t)((double)p.s.reward_state[eN + i] * 0.9); // :130
     }
     __syncthreads();
+    if (p.scaled) {
+        // A deposit that landed on a WALL cell in the previous update is visible to exactly one
+        // observation and is zeroed by this update's Walls pass (walls.py:30): clear it now.
+        for (int i = tid; i < N; i += T) {
+            const int32_t wc = p.s.walldep_cell[eN + i];
+            if (wc >= 0) {
+                for (int c = 0; c < C; ++c) out[(size_t)wc * C + c] = 0.0f;
+                p.s.walldep_cell[eN + i] = -1;
+            }
+        }
+        __syncthreads();
+    }
     double gain = 0.0;
     for (int i = tid; i < N; i += T) {
         const uint32_t cell = (uint32_t)((int)p.s.x[eN + i] * H + (int)p.s.y[eN + i]);
         if (lww_winner(hkeys, hvals, (uint32_t)p.HT - 1, cell) == (uint32_t)i) {
-            for (int c = 0; c < C; ++c) {
-                const float a = p.s.activation[(eN + i) * C + c];
-                if (a != 0.0f) {
-                    float v = out[(size_t)cell * C + c] + a;
-                    if (p.has_max_val) v = fminf(v, (float)p.max_val);
-                    out[(size_t)cell * C + c] = v;
+            if (!p.scaled) {
+                for (int c = 0; c < C; ++c) {
+                    const float a = p.s.activation[(eN + i) * C + c];
+                    if (a != 0.0f) {
+                        float v = out[(size_t)cell * C + c] + a;
+                        if (p.has_max_val) v = fminf(v, (float)p.max_val);
+                        out[(size_t)cell * C + c] = v;
+                    }
                 }
+            } else {
+                // grid holds u = v / f0^S_write.  Value after this update's (conceptual) sweep:
+                // v = u * f0^(S+1), zero below the cut (the per-step cut is monotone, so testing the
+                // current value equals testing every intermediate one); wall cells hold no
+                // pheromone at deposit time (walls.py:30).
+                const bool on_wall = test_bit(walls, cell);
+                bool wrote = false;
+                for (int c = 0; c < C; ++c) {
+                    const float a = p.s.activation[(eN + i) * C + c];
+                    if (a != 0.0f) {
+                        double v = (double)out[(size_t)cell * C + c] * p.g_dep;
+                        if (v < p.threshold || on_wall) v = 0.0;
+                        v += (double)a;
+                        if (p.has_max_val) v = fmin(v, p.max_val);
+                        out[(size_t)cell * C + c] = (float)(v * p.inv_g_dep);
+                        wrote = true;
+                    } else if (on_wall) {
+                        out[(size_t)cell * C + c] = 0.0f;
+                    }
+                }
+                if (on_wall && wrote) p.s.walldep_cell[eN + i] = (int32_t)cell;
             }
         }
         // ---- Anthill.update (anthill.py:41-46), sparse: after the first full collect the only
@@ -819,6 +865,28 @@ k_sweep_tiled(const KP p, const float *__restrict__ in, float *__restrict__ out)
     }
 }
 
+// Scaled mode helpers (rare, full-grid): zero the wall cells of the grid (first update after a
+// reset that supplied an initial pheromone grid) and re-base the units when f0^S gets tiny.
+__global__ void __launch_bounds__(256) k_phero_wall_clear(const KP p)
+{
+    const size_t G = (size_t)p.W * p.H, n = (size_t)p.E * G;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t e = i / G, g = i - e * G;
+        if (test_bit(p.s.walls_bits + e * p.words, (uint32_t)g))
+            for (int c = 0; c < p.C; ++c) p.s.phero[0][i * p.C + c] = 0.0f;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_phero_renorm(const KP p)
+{
+    // u := materialised value (units of f0^0); the host then restarts S at 0.
+    const size_t n = (size_t)p.E * p.W * p.H * p.C;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const double v = (double)p.s.phero[0][i] * p.g_now;
+        p.s.phero[0][i] = v < p.threshold ? 0.0f : (float)v;
+    }
+}
+
 // ===================================================================================
 // reset / state I/O (not on the hot path)
 // ===================================================================================
@@ -835,6 +903,7 @@ __global__ void k_reset_ants(const KP p, const double *__restrict__ xyt, const d
         p.s.mandibles[i] = 0; p.s.reward_state[i] = 0;
         p.s.seed[i] = (float)seed[i];
         p.s.dirty_cell[i] = -1;
+        p.s.walldep_cell[i] = -1;
         for (int c = 0; c < p.C; ++c) p.s.activation[i * p.C + c] = 0.0f;
         const double dx = x - (double)p.s.anthill_xyr[3 * e + 0], dy = y - (double)p.s.anthill_xyr[3 * e + 1];
         p.s.prev_dist[i] = sqrt(dx * dx + dy * dy); // reward_custom.py:77
@@ -928,7 +997,12 @@ __global__ void k_read_state(const KP p, const int which, const int cur, void *_
     case ANTSRL_S_PHERO: // interleaved [E][G][C] -> canonical [E][C][G]
         for (size_t i = t0; i < EG * p.C; i += stride) {
             const size_t e = i / (G * p.C), rem = i - e * G * p.C, c = rem / G, g = rem - c * G;
-            ((float *)dstv)[i] = p.s.phero[cur][(e * G + g) * p.C + c];
+            float v = p.s.phero[cur][(e * G + g) * p.C + c];
+            if (p.scaled) {
+                v *= (float)p.g_now;
+                if (v < (float)p.threshold) v = 0.0f;
+            }
+            ((float *)dstv)[i] = v;
         }
         break;
     case ANTSRL_S_FOOD: for (size_t i = t0; i < EG; i += stride) ((float *)dstv)[i] = p.s.food[i]; break;
@@ -1103,6 +1177,19 @@ hipError_t antsrl_launch_update(const KP &p, const double *jitter, int out_buf, 
 hipError_t antsrl_launch_collect_full(const KP &p, hipStream_t st)
 {
     hipLaunchKernelGGL(k_collect_full, dim3(p.E), dim3(256), 0, st, p);
+    return hipGetLastError();
+}
+
+static inline unsigned grid_for(size_t n);
+hipError_t antsrl_launch_phero_wall_clear(const KP &p, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_phero_wall_clear, dim3(grid_for((size_t)p.E * p.W * p.H)), dim3(256), 0, st, p);
+    return hipGetLastError();
+}
+
+hipError_t antsrl_launch_phero_renorm(const KP &p, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_phero_renorm, dim3(grid_for((size_t)p.E * p.W * p.H * p.C)), dim3(256), 0, st, p);
     return hipGetLastError();
 }
 

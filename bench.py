@@ -121,6 +121,8 @@ def main():
     ap.add_argument("--envs", type=int, default=0, help="override envs per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--explicit-sweep", action="store_true",
+                    help="force the per-step pheromone sweep kernel (default: scaled units, no sweep)")
     args = ap.parse_args()
 
     import numpy as np
@@ -146,7 +148,8 @@ def main():
 
     W_ = CONFIGS[args.config]
     E = args.envs or W_["E"]
-    extra = dict(n_rocks=W_["R"], deposit_strength=256.0, max_time=1 << 30)
+    extra = dict(n_rocks=W_["R"], deposit_strength=256.0, max_time=1 << 30,
+                 phero_mode=cm.PHERO_EXPLICIT_SWEEP if args.explicit_sweep else cm.PHERO_AUTO)
     if W_["radius3"]:
         ax = np.arange(-3, 4)
         g = np.exp(-(ax[:, None] ** 2 + ax[None, :] ** 2) / 4.5)
@@ -202,6 +205,8 @@ def main():
         if timing:
             ms = np.array([[evs.elapsed_ms(4 * t + i, 4 * t + i + 1) for i in range(3)] for t in range(K)])
             kern = dict(sweep=float(ms[:, 0].mean()), act=float(ms[:, 1].mean()), update=float(ms[:, 2].mean()))
+            if cm.uses_scaled_units(cfg):
+                kern.pop("sweep")  # scaled pheromone units: no sweep kernel is launched at all
             dom = max(kern, key=kern.get)
             names = dict(sweep="k_sweep0" if cfg.filter_radius == 0 else "k_sweep_tiled", act="k_act", update="k_update")
             achieved = ab[dom] * E / (kern[dom] * 1e-3) / 1e9
@@ -225,6 +230,8 @@ def main():
             "config": {"workload": W_["desc"], "envs_per_gpu": E, "ants": cfg.n_ants, "grid": [cfg.w, cfg.h],
                        "pheromone_channels": cfg.n_phero, "rocks": cfg.n_rocks, "obs_channels": cfg.n_channels,
                        "filter_radius": cfg.filter_radius, "reward": "ExplorationReward",
+                       "pheromone_update": "scaled units (no per-step sweep)" if cm.uses_scaled_units(cfg)
+                       else "explicit sweep kernel",
                        "policy": "uniform random, pre-generated on device",
                        "parallelism": "env-sharded x%d, reward/done all-gather" % world},
             "roofline": roofline,

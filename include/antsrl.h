@@ -59,6 +59,14 @@ enum {
     ANTSRL_CH_ROCKS = 5    /* RL_api.py:132-135  any(dist < radius)      */
 };
 
+/* Pheromone.update strategy.  With the shipped centre-only DIFFUSE_FILTER (DIFFUSE_FACTOR = 0,
+ * pheromone.py:5-10) the update is a per-cell multiply by f0 = 1 - EVAP_FACTOR plus a cut at
+ * 0.01.  AUTO then stores the grid in units of f0^S (S = updates so far), so evaporation costs no
+ * per-step pass over the grid at all; values are materialised (v = u * f0^S, zero below the cut)
+ * wherever they are read.  EXPLICIT_SWEEP forces the streaming sweep kernel; filters with a
+ * radius always use the LDS-tiled sweep. */
+enum { ANTSRL_PHERO_AUTO = 0, ANTSRL_PHERO_EXPLICIT_SWEEP = 1 };
+
 /* reward kinds (environment/rewards/) */
 enum {
     ANTSRL_REWARD_NONE = 0,        /* Reward base: zeros, reward.py:19,38       */
@@ -111,7 +119,7 @@ typedef struct AntsCfg {
 
     /* reward */
     int32_t reward_kind; /* ANTSRL_REWARD_* */
-    int32_t _pad1;
+    int32_t phero_mode;  /* ANTSRL_PHERO_AUTO (0) or ANTSRL_PHERO_EXPLICIT_SWEEP (1), see below */
     double reward_threshold; /* RLApi.reward_threshold, RL_api.py:32,203 */
     double fct_explore, fct_food, fct_anthill, fct_explore_holding, fct_headinganthill;
 

@@ -43,8 +43,13 @@ def test_workspace_bytes_and_validation(lib):
     cfg = make_cfg(1024, 512, 256, 256, n_rocks=8)
     n = C.c_size_t()
     assert lib.antsrl_workspace_bytes(C.byref(cfg), C.byref(n)) == 0
-    # 2 pheromone buffers + food + bitmaps + ant SoA, ~1.3 GiB
-    assert 1.2 * 2 ** 30 < n.value < 1.5 * 2 ** 30
+    # scaled pheromone units: ONE pheromone buffer + food + bitmaps + ant SoA, ~0.8 GiB
+    assert 0.75 * 2 ** 30 < n.value < 0.9 * 2 ** 30
+    from antsrl_amd.config import PHERO_EXPLICIT_SWEEP
+    cfg2 = make_cfg(1024, 512, 256, 256, n_rocks=8, phero_mode=PHERO_EXPLICIT_SWEEP)
+    n2 = C.c_size_t()
+    assert lib.antsrl_workspace_bytes(C.byref(cfg2), C.byref(n2)) == 0
+    assert n2.value - n.value == 1024 * 256 * 256 * 2 * 4  # the ping-pong buffer of the explicit sweep
     bad = cfg.copy()
     bad.n_phero = 9
     assert lib.antsrl_workspace_bytes(C.byref(bad), C.byref(n)) == -1

@@ -81,12 +81,22 @@ def check_state(env, cfg, F, t, meta, ctx, envs, with_phero):
                 ctx, (~ok).sum(), np.abs(ph[e] - F["phero"][t])[~ok].max())
 
 
+def _modes():
+    from antsrl_amd import config as cm
+    return [cm.PHERO_AUTO, cm.PHERO_EXPLICIT_SWEEP]
+
+
+@pytest.mark.parametrize("mode", [0, 1], ids=["auto", "explicit_sweep"])
 @pytest.mark.parametrize("name", fixture_names())
-def test_hip_matches_reference_golden(torch_mod, name):
-    """Replay every recorded reference run through antsrl_step / antsrl_update / antsrl_observe."""
+def test_hip_matches_reference_golden(torch_mod, name, mode):
+    """Replay every recorded reference run through antsrl_step / antsrl_update / antsrl_observe,
+    with the scaled pheromone units (auto) and with the explicit per-step sweep."""
     from antsrl_amd.batched import BatchedAntsEnv
     n_envs = 3
     cfg, init, F, meta = load_fixture(name, n_envs)
+    if mode == 1 and cfg.filter_radius != 0:
+        pytest.skip("filters with a radius always use the tiled sweep")
+    cfg.phero_mode = mode
     env = BatchedAntsEnv(cfg)
     env.reset(init)
     from antsrl_amd import config as cm
@@ -167,6 +177,9 @@ def _compare_with_oracle(torch_mod, cfg, init, steps, seed, jitter_mode):
         np.testing.assert_array_equal(_cpu(env.read_state(cm.S_HOLDING)), orc.holding, err_msg=ctx)
         np.testing.assert_array_equal(_cpu(env.read_state(cm.S_FOOD)), orc.food, err_msg=ctx)
         np.testing.assert_array_equal(_cpu(env.read_state(cm.S_ANTHILL_FOOD)), orc.anthill_food, err_msg=ctx)
+        if cfg.w * cfg.h <= 4096:  # small grids: the pheromone grid after every update
+            okp = phero_close(_cpu(env.read_state(cm.S_PHERO)), orc.phero, threshold=cfg.phero_threshold)
+            assert okp.all(), "%s pheromone: %d cells off" % (ctx, (~okp).sum())
     np.testing.assert_array_equal(_cpu(env.read_state(cm.S_EXPLORED)), orc.explored)
     np.testing.assert_array_equal(_cpu(env.read_state(cm.S_MANDIBLES)), orc.mandibles)
     ok = phero_close(_cpu(env.read_state(cm.S_PHERO)), orc.phero, threshold=cfg.phero_threshold)
@@ -201,6 +214,29 @@ def test_config4_shape_radius3_vs_oracle(torch_mod):
     g = g / g.sum() * 0.999
     cfg = make_cfg(2, 1024, 512, 512, filt=g, deposit_strength=256.0)
     _compare_with_oracle(torch_mod, cfg, synth_init(cfg, seed=11), steps=6, seed=8, jitter_mode="builtin")
+
+
+def test_scaled_units_edge_cases(torch_mod):
+    """Scaled pheromone units against the oracle where they need care: an initial grid with
+    pheromone on wall cells, ants that START on wall cells (their deposits live for exactly one
+    observation), fast decay forcing several re-basings of the units, f0 == 1."""
+    from antsrl_amd import config as cm
+    from antsrl_amd.synth import synth_init
+    for f0, steps, max_val in [(0.999, 12, 255.0), (0.55, 200, 255.0), (1.0, 10, 255.0), (0.9, 30, 100.0)]:
+        cfg = cm.make_cfg(3, 48, 40, 40, n_rocks=2, deposit_strength=256.0, filt=np.array([[f0]]),
+                          phero_max_val=max_val)
+        init = synth_init(cfg, seed=21, wall_density=0.15, n_food_discs=4, food_rmin=2, food_rmax=4)
+        rng = np.random.default_rng(4)
+        init["phero"] = (rng.random((3, 2, 40, 40)) * 300 * (rng.random((3, 2, 40, 40)) < 0.3)).astype(np.float32)
+        if max_val is not None:
+            init["phero"] = np.minimum(init["phero"], max_val)
+        # put a third of the ants exactly on wall cells
+        for e in range(3):
+            wx, wy = np.nonzero(init["walls"][e])
+            pick = rng.integers(0, len(wx), 16)
+            init["ants_xyt"][e, :16, 0] = wx[pick] + 0.5
+            init["ants_xyt"][e, :16, 1] = wy[pick] + 0.5
+        _compare_with_oracle(torch_mod, cfg, init, steps=steps, seed=9, jitter_mode="builtin")
 
 
 def test_small_and_odd_shapes(torch_mod):
