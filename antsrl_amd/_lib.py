@@ -7,7 +7,8 @@ import os
 
 from .config import AntsCfg, AntsInit
 
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libantsrl_hip.so")
+LIB_PATH = os.environ.get("ANTSRL_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib",
+                                                        "libantsrl_hip.so")  # ANTSRL_LIB: A/B builds
 
 #: every symbol include/antsrl.h declares
 EXPORTS = ("antsrl_abi_version", "antsrl_cfg_size", "antsrl_last_error", "antsrl_workspace_bytes", "antsrl_create",

@@ -7,6 +7,7 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 #include <new>
 
@@ -14,7 +15,8 @@
 
 // launchers (antsrl_kernels.hip)
 hipError_t antsrl_launch_act(const KP &p, const int8_t *rot, const int8_t *ph, int cur, float *obs,
-                             float *agent_state, float *reward, uint8_t *done, int flags, hipStream_t st);
+                             float *agent_state, float *reward, uint8_t *done, int flags,
+                             const double *jitter, int out_buf, hipStream_t st);
 bool antsrl_act_fits(const KP &p);
 hipError_t antsrl_launch_sweep(const KP &p, int cur, hipStream_t st);
 hipError_t antsrl_launch_update(const KP &p, const double *jitter, int out_buf, hipStream_t st);
@@ -236,19 +238,23 @@ extern "C" int antsrl_reset(AntsHandle *h, const AntsInit *init, void *stream)
 static int not_reset() { return fail(ANTSRL_E_INVALID, "antsrl_reset has not been called on this handle"); }
 
 static int do_step(AntsHandle *h, const int8_t *rot, const int8_t *ph, float *obs, float *agent_state,
-                   float *reward, uint8_t *done, hipStream_t st)
+                   float *reward, uint8_t *done, hipStream_t st, bool fused_update = false,
+                   const double *jitter = nullptr)
 {
     if (ph && h->p.C != 2) // Ants.activate_pheromone hard-codes two channels, ants.py:89-96
         return fail(ANTSRL_E_INVALID, "pheromone actions need exactly 2 pheromone channels (ants.py:89-96)");
     if (h->steps_since_update > 0) h->need_full_collect = true; // dirty-cell list would be overwritten
+    static const int ablate = getenv("ANTSRL_ABLATE") ? atoi(getenv("ANTSRL_ABLATE")) & ~7 : 0; // profiling only
     hipError_t e = antsrl_launch_act(h->p, rot, ph, h->cur, obs, agent_state, reward, done,
-                                     ACT_STEP | (obs ? ACT_HAS_OBS : 0), st);
+                                     ACT_STEP | (obs ? ACT_HAS_OBS : 0) | (fused_update ? ACT_FUSED_UPDATE : 0) | ablate,
+                                     jitter, h->p.scaled ? 0 : h->cur ^ 1, st);
     if (e != hipSuccess) return hip_fail(e, "step");
     h->steps_since_update++;
     return ANTSRL_OK;
 }
 
-static int do_update(AntsHandle *h, const double *jitter, hipStream_t st, bool sweep_done)
+static int do_update(AntsHandle *h, const double *jitter, hipStream_t st, bool sweep_done,
+                     bool update_fused = false)
 {
     hipError_t e;
     if (h->p.scaled) {
@@ -268,8 +274,10 @@ static int do_update(AntsHandle *h, const double *jitter, hipStream_t st, bool s
         e = antsrl_launch_sweep(h->p, h->cur, st);
         if (e != hipSuccess) return hip_fail(e, "pheromone sweep");
     }
-    e = antsrl_launch_update(h->p, jitter, h->p.scaled ? 0 : h->cur ^ 1, st);
-    if (e != hipSuccess) return hip_fail(e, "update");
+    if (!update_fused) {
+        e = antsrl_launch_update(h->p, jitter, h->p.scaled ? 0 : h->cur ^ 1, st);
+        if (e != hipSuccess) return hip_fail(e, "update");
+    }
     if (h->p.scaled) {
         h->sweeps++;
         set_decay(h);
@@ -298,7 +306,7 @@ extern "C" int antsrl_observe(AntsHandle *h, float *obs, float *agent_state, flo
     if (!h) return fail(ANTSRL_E_INVALID, "NULL handle");
     if (!h->is_reset) return not_reset();
     hipError_t e = antsrl_launch_act(h->p, nullptr, nullptr, h->cur, obs, agent_state, reward, nullptr,
-                                     obs ? ACT_HAS_OBS : 0, (hipStream_t)stream);
+                                     obs ? ACT_HAS_OBS : 0, nullptr, 0, (hipStream_t)stream);
     if (e != hipSuccess) return hip_fail(e, "observe");
     return ANTSRL_OK;
 }
@@ -328,10 +336,23 @@ extern "C" int antsrl_step_update(AntsHandle *h, const int8_t *rotation, const i
         if (e != hipSuccess) return hip_fail(e, "pheromone sweep");
     }
     if (timed) (void)hipEventRecord(h->ev[1], st);
-    int rc = do_step(h, rotation, phero, obs, agent_state, reward, done, st);
+    // Fuse Environment.update into the same launch unless the one-off wall clear of an initial
+    // pheromone grid has to run between this step's observation and this update's deposits.
+    // Measured on MI355X (c3): fusing is SLOWER (0.44 vs 0.41 ms/step) — with two workgroups per CU
+    // the update's latency-bound phases idle half the CU, while as its own launch they overlap
+    // across all resident workgroups.  Kept selectable (ANTSRL_FUSE_UPDATE=1) for re-evaluation.
+    static const bool want_fuse = getenv("ANTSRL_FUSE_UPDATE") && atoi(getenv("ANTSRL_FUSE_UPDATE")) != 0;
+    const bool fuse = want_fuse && !(h->p.scaled && h->need_wall_clear);
+    if (fuse && h->p.scaled && h->p.g_dep < 1e-20) { // re-base before the launch (value-preserving)
+        hipError_t e = antsrl_launch_phero_renorm(h->p, st);
+        if (e != hipSuccess) return hip_fail(e, "pheromone renorm");
+        h->sweeps = 0;
+        set_decay(h);
+    }
+    int rc = do_step(h, rotation, phero, obs, agent_state, reward, done, st, fuse, wall_jitter);
     if (rc) return rc;
     if (timed) (void)hipEventRecord(h->ev[2], st);
-    rc = do_update(h, wall_jitter, st, true);
+    rc = do_update(h, wall_jitter, st, true, fuse);
     if (timed) (void)hipEventRecord(h->ev[3], st);
     return rc;
 }

@@ -60,3 +60,9 @@ struct KP {
 // k_act flags
 #define ACT_STEP 1        // run RLApi.step's action phases before observing
 #define ACT_HAS_OBS 2     // obs pointer valid
+#define ACT_FUSED_UPDATE 4 // run Environment.update of the same step at the tail of the launch
+// profiling ablations (env ANTSRL_ABLATE, results are WRONG with any of them set; bench/tests never set it)
+#define ACT_ABL_NO_ITEMS 256   // skip the perception phase
+#define ACT_ABL_NO_GATHER 512  // no pheromone/food gathers
+#define ACT_ABL_NO_STORE 1024  // no observation stores
+#define ACT_ABL_NO_EXPLORE 2048 // no explored-map test/mark

@@ -105,11 +105,13 @@ __device__ __forceinline__ uint32_t lww_winner(const uint32_t *keys, const uint3
 
 __device__ __forceinline__ void wave_lds_sync()
 {
-    // LDS hand-off between lanes of ONE wave: make the writes visible, keep the compiler
-    // from moving LDS accesses across this point.
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    // LDS hand-off between lanes of ONE wave.  A wave's LDS instructions execute in issue order,
+    // so no s_waitcnt is needed — only a fence that keeps the COMPILER from reordering the staging
+    // writes and the copy-out reads.  Wavefront scope on purpose: a workgroup-scope release would
+    // also drain the wave's outstanding global stores (vmcnt(0)) and stall it behind the
+    // observation writes of the previous round.
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
 __host__ __device__ __forceinline__ size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -118,6 +120,16 @@ __host__ __device__ __forceinline__ size_t align_up(size_t v, size_t a) { return
 // k_act — RLApi.step (RL_api.py:168-204) / RLApi.observation (RL_api.py:96-165)
 // one workgroup per environment
 // ===================================================================================
+__host__ __device__ inline size_t update_scratch_bytes(int HT, int R, int nwaves)
+{
+    return align_up(8 * (size_t)HT, 16) + 16 * (size_t)(R > 0 ? R : 1) + 8 * (size_t)nwaves +
+           4 * (size_t)nwaves + 16;
+}
+
+template <int C>
+__device__ __forceinline__ void update_env(const KP &p, const int e, const double *__restrict__ wall_jitter,
+                                           const int out_buf, unsigned char *smem);
+
 struct __align__(16) AntFrame { double cx, cy, ct, st; }; // perception centre, cos/sin(theta + pi/2)
 struct __align__(16) CellOff { double px, py; };            // rotated-grid offsets, RL_api.py:92-93
 
@@ -129,15 +141,17 @@ struct ActLds {
     uint32_t *b_pres, *b_old, *b_new;  // [words] presence / explored (pre-step) / explored (marked)
     uint32_t *b_walls, *b_area;        // [words] (only when STATIC_LDS)
     uint8_t *t_mask;                   // [PP]
+    double *rock;                      // [3R] cx, cy, radius of this env's rocks
     uint32_t *hkeys, *hvals;           // [HT] — aliases `stage`
-    float *stage;                      // [nwaves*64*K]
+    float *stage;                      // [nwaves][stage_stride]: one ant's K*PP outputs (+ alignment pad)
+    uint32_t stage_stride;             // floats per wave, multiple of 4
 };
 
-#define ACT_UNROLL 2                 // work items per lane per iteration (gathers in flight)
+#define ACT_UNROLL 2                 // ants in flight per wave (all their gathers are issued before the first is consumed)
 #define ACT_ITEMS (64 * ACT_UNROLL)  // work items per wave per iteration
 
-__host__ __device__ inline size_t act_lds_bytes(int N, int PP, int words, int HT, int K, int nwaves,
-                                                bool static_lds, ActLds *o, unsigned char *base)
+__host__ __device__ __forceinline__ size_t act_lds_bytes(int N, int PP, int words, int HT, int K, int nwaves,
+                                                bool static_lds, ActLds *o, unsigned char *base, int R = 0)
 {
     size_t off = 0;
     auto take = [&](size_t bytes) {
@@ -155,7 +169,9 @@ __host__ __device__ inline size_t act_lds_bytes(int N, int PP, int words, int HT
         a_a = take(4 * (size_t)words);
     }
     size_t a_mask = take((size_t)PP);
-    size_t hash_b = 8 * (size_t)HT, stage_b = 4 * (size_t)nwaves * 64 * K;
+    size_t a_rock = take(24 * (size_t)(R > 0 ? R : 1));
+    const size_t stride = ((size_t)PP * K + 3 + 3) / 4 * 4; // row + up to 3 floats of misalignment
+    size_t hash_b = update_scratch_bytes(HT, R, nwaves), stage_b = 4 * (size_t)nwaves * stride;
     size_t a_u = take(hash_b > stage_b ? hash_b : stage_b);
     if (o) {
         o->frame = (AntFrame *)(base + a_fr);
@@ -165,6 +181,8 @@ __host__ __device__ inline size_t act_lds_bytes(int N, int PP, int words, int HT
         o->b_new = (uint32_t *)(base + a_new);
         o->b_walls = (uint32_t *)(base + a_w); o->b_area = (uint32_t *)(base + a_a);
         o->t_mask = base + a_mask;
+        o->rock = (double *)(base + a_rock);
+        o->stage_stride = (uint32_t)stride;
         o->hkeys = (uint32_t *)(base + a_u); o->hvals = o->hkeys + HT;
         o->stage = (float *)(base + a_u);
     }
@@ -177,11 +195,14 @@ __host__ __device__ inline size_t act_lds_bytes(int N, int PP, int words, int HT
 #define LAYOUT_DEFAULT 1       // [Ants, Phero0, Phero1, Anthill, Walls, Food]   (generator order)
 #define LAYOUT_DEFAULT_ROCKS 2 // ... + [CircleObstacles]
 
-template <int C, bool STATIC_LDS, int LAYOUT>
+// FAST selects the software-pipelined perception loop (see phase 3); the two loops live in
+// separate instantiations on purpose: with both in one kernel the optimiser stops scalarising the
+// LDS carve (`ActLds`), its pointers go through scratch and every LDS access degrades to flat_*.
+template <int C, bool STATIC_LDS, int LAYOUT, bool FAST>
 __global__ void __launch_bounds__(1024)
 k_act(const KP p, const int8_t *__restrict__ rotation, const int8_t *__restrict__ phero_act, const int cur,
       float *__restrict__ obs, float *__restrict__ agent_state, float *__restrict__ reward,
-      uint8_t *__restrict__ done, const int flags)
+      uint8_t *__restrict__ done, const int flags, const double *__restrict__ wall_jitter, const int out_buf)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const int e = blockIdx.x, tid = threadIdx.x, T = blockDim.x;
@@ -189,7 +210,7 @@ k_act(const KP p, const int8_t *__restrict__ rotation, const int8_t *__restrict_
     const int N = p.N, W = p.W, H = p.H, K = p.K, P = p.P, PP = p.PP, R = p.R;
     const size_t G = (size_t)W * H;
     ActLds L;
-    act_lds_bytes(N, PP, p.words, p.HT, K, nwaves, STATIC_LDS, &L, smem);
+    act_lds_bytes(N, PP, p.words, p.HT, K, nwaves, STATIC_LDS, &L, smem, R);
 
     const size_t eN = (size_t)e * N;
     const uint32_t *g_walls = p.s.walls_bits + (size_t)e * p.words;
@@ -219,6 +240,11 @@ k_act(const KP p, const int8_t *__restrict__ rotation, const int8_t *__restrict_
         L.off[q].px = (double)(b - p.r) * p.delta; // coords[a][b] = (arange[b], arange[a]) * DELTA
         L.off[q].py = (double)(a - p.r) * p.delta;
         L.t_mask[q] = p.has_mask ? p.mask[q] : (uint8_t)1;
+    }
+    for (int q = tid; q < R; q += T) {
+        L.rock[3 * q + 0] = p.s.rock_cx[(size_t)e * R + q];
+        L.rock[3 * q + 1] = p.s.rock_cy[(size_t)e * R + q];
+        L.rock[3 * q + 2] = p.s.rock_r[(size_t)e * R + q];
     }
     if (do_step)
         for (int h = tid; h < p.HT; h += T) {
@@ -316,8 +342,8 @@ k_act(const KP p, const int8_t *__restrict__ rotation, const int8_t *__restrict_
         if (R > 0) {
             const bool border = xf - margin < 0 || yf - margin < 0 || xf + margin >= W || yf + margin >= H;
             for (int q = 0; q < R; ++q) {
-                const double dx = p.s.rock_cx[(size_t)e * R + q] - xf, dy = p.s.rock_cy[(size_t)e * R + q] - yf;
-                const double rr = p.s.rock_r[(size_t)e * R + q] + margin;
+                const double dx = L.rock[3 * q + 0] - xf, dy = L.rock[3 * q + 1] - yf;
+                const double rr = L.rock[3 * q + 2] + margin;
                 if (border || dx * dx + dy * dy < rr * rr) rm |= 1u << q;
             }
         }
@@ -325,140 +351,303 @@ k_act(const KP p, const int8_t *__restrict__ rotation, const int8_t *__restrict_
     }
     __syncthreads();
 
-    // ---- phase 3: perception gather, RL_api.py:109-148.  Work item = (ant, cell); a wave takes
-    //      ACT_ITEMS consecutive items (ACT_UNROLL per lane, so several gathers are in flight),
-    //      stages their K outputs in LDS and writes them as one contiguous, 16-byte-vectorised
-    //      run of the observation tensor.
-    const uint32_t total = (uint32_t)N * (uint32_t)PP;
-    const uint32_t pp_magic = (uint32_t)((0x100000000ull + (uint32_t)PP - 1) / (uint32_t)PP); // item/PP by mul-hi
-    float *stage = L.stage + (size_t)wave * 64 * K;
-    float *obs_env = (flags & ACT_HAS_OBS) ? obs + (size_t)e * total * K : nullptr;
-    const bool vec_ok = (((size_t)total * K) % 4 == 0);
+    // ---- phase 3: perception gather, RL_api.py:109-148.  One WAVE per ant, one LANE per perceived
+    //      cell (49 of 64 lanes at the reference's 7x7): the cell's offsets, mask bit and output slot
+    //      are per-lane constants held in registers, the ant's frame is wave-uniform (LDS
+    //      broadcast), ACT_UNROLL ants are in flight per wave so every gather is issued before the
+    //      first is consumed.  Each ant's K*PP outputs are staged in LDS and leave as 16-byte stores.
+    float *obs_env = (flags & ACT_HAS_OBS) ? obs + (size_t)e * (size_t)N * PP * K : nullptr;
     const float inv_max = 1.0f / (float)p.max_val;
     const float g_now = (float)p.g_now;                       // scaled mode: v = u * f0^S ...
     const float cut = p.scaled ? (float)p.threshold : 0.0f;   // ... and 0 below the 0.01 cut
-    for (uint32_t base = (uint32_t)wave * ACT_ITEMS; base < total; base += (uint32_t)nwaves * ACT_ITEMS) {
-        uint32_t ant[ACT_UNROLL], cell[ACT_UNROLL];
-        int ixv[ACT_UNROLL], iyv[ACT_UNROLL];
-        bool valid[ACT_UNROLL], vis[ACT_UNROLL];
-        float pv[ACT_UNROLL][C];
-        float fd[ACT_UNROLL];
+    const bool abl_gather = flags & ACT_ABL_NO_GATHER, abl_store = flags & ACT_ABL_NO_STORE;
+    const bool abl_explore = flags & ACT_ABL_NO_EXPLORE;
+    const int npass = (PP + 63) >> 6;
+    const uint32_t row = (uint32_t)PP * (uint32_t)K;            // floats per ant
+    float *stage = L.stage + (size_t)wave * L.stage_stride;
+    const bool wrap_fast = W > 4 * (p.r + 4) && H > 4 * (p.r + 4) && p.fwd_delta < W / 4 && p.fwd_delta < H / 4 &&
+                           p.fwd_delta > -W / 4 && p.fwd_delta > -H / 4 && p.delta < 2.0; // one conditional add wraps
+    // Fast path (single pass: PP <= 64, row <= 508 floats — the reference's 7x7 with up to 10
+    // channels): software-pipelined by one group of ACT_UNROLL ants.  Everything that touches
+    // global memory is STRAIGHT-LINE and unconditional (out-of-range ants/lanes are clamped onto
+    // valid ones and redo identical work: benign duplicate stores), so the compiler can count
+    // outstanding operations: the wait for group g's gathers is a `vmcnt(n)` that leaves group
+    // g+1's gathers AND group g-1's observation stores in flight.  (vmcnt retires in order and
+    // counts stores: an uncounted wait would make every gather wait for the previous stores.)
+    if (FAST) { // host guarantees: npass == 1, 8 <= row <= 508, obs != nullptr
+        const int q = lane < PP ? lane : PP - 1;            // lanes beyond the perception clamp onto its last cell
+        const CellOff of = L.off[q];
+        const bool mask_q = L.t_mask[q] != 0;
+        const uint32_t qK = (uint32_t)q * K;
+        // Two register sets (current / prefetched group); plain arrays with compile-time indices only,
+        // so they stay in VGPRs (a struct passed by reference ends up in scratch).
+#define ACT_FETCH(G0, CELL, IXV, IYV, PVV, FDV)                                                          \
+    {                                                                                                    \
+        _Pragma("unroll") for (int u = 0; u < ACT_UNROLL; ++u)                                           \
+        {                                                                                                \
+            const int i_ = min((G0) + u, N - 1);                                                         \
+            const AntFrame fr = L.frame[i_]; /* wave-uniform address: LDS broadcast */                   \
+            const double rx = fr.ct * of.px - fr.st * of.py; /* RL_api.py:110-111 */                     \
+            const double ry = fr.st * of.px + fr.ct * of.py;                                             \
+            int ix = (int)rint(rx + fr.cx), iy = (int)rint(ry + fr.cy); /* :114-117 half to even */      \
+            if (wrap_fast) { /* :118-119 */                                                              \
+                ix += ix < 0 ? W : 0; ix -= ix >= W ? W : 0;                                             \
+                iy += iy < 0 ? H : 0; iy -= iy >= H ? H : 0;                                             \
+            } else {                                                                                     \
+                ix = wrap_index(ix, W); iy = wrap_index(iy, H);                                          \
+            }                                                                                            \
+            IXV[u] = ix; IYV[u] = iy;                                                                    \
+            CELL[u] = (uint32_t)(ix * H + iy);                                                           \
+        }                                                                                                \
+        /* unconditional gathers (masked cells too: in bounds, discarded) */                             \
+        _Pragma("unroll") for (int u = 0; u < ACT_UNROLL; ++u)                                           \
+        {                                                                                                \
+            if (C == 2) {                                                                                \
+                const float2 t = *reinterpret_cast<const float2 *>(ph + (size_t)CELL[u] * 2);            \
+                PVV[u][0] = t.x; PVV[u][C - 1] = t.y;                                                    \
+            } else {                                                                                     \
+                _Pragma("unroll") for (int c = 0; c < C; ++c) PVV[u][c] = ph[(size_t)CELL[u] * C + c];  \
+            }                                                                                            \
+            FDV[u] = food[CELL[u]];                                                                      \
+        }                                                                                                \
+    }
+        uint32_t c_cell[ACT_UNROLL], n_cell[ACT_UNROLL];
+        int c_ix[ACT_UNROLL], c_iy[ACT_UNROLL], n_ix[ACT_UNROLL], n_iy[ACT_UNROLL];
+        float c_pv[ACT_UNROLL][C], n_pv[ACT_UNROLL][C], c_fd[ACT_UNROLL], n_fd[ACT_UNROLL];
+        const int gstep = nwaves * ACT_UNROLL;
+        ACT_FETCH(wave * ACT_UNROLL, c_cell, c_ix, c_iy, c_pv, c_fd)
+        for (int i0 = wave * ACT_UNROLL; i0 < N; i0 += gstep) {
+            // prefetch the next group (clamped: harmless re-read at the end)
+            ACT_FETCH(min(i0 + gstep, N - 1), n_cell, n_ix, n_iy, n_pv, n_fd)
 #pragma unroll
-        for (int u = 0; u < ACT_UNROLL; ++u) {
-            const uint32_t item = base + u * 64 + lane;
-            valid[u] = item < total;
-            const uint32_t it = valid[u] ? item : 0u;
-            const uint32_t i = __umulhi(it, pp_magic), q = it - i * (uint32_t)PP; // exact: it < 2^32/(PP*PP)
-            const AntFrame fr = L.frame[i];
-            const CellOff of = L.off[q];
-            const double rx = fr.ct * of.px - fr.st * of.py; // RL_api.py:110-111
-            const double ry = fr.st * of.px + fr.ct * of.py;
-            ixv[u] = wrap_index((int)rint(rx + fr.cx), W); // :114-119 (np.round = half to even)
-            iyv[u] = wrap_index((int)rint(ry + fr.cy), H);
-            cell[u] = (uint32_t)(ixv[u] * H + iyv[u]);
-            ant[u] = i;
-            vis[u] = valid[u] && obs_env && L.t_mask[q];
-        }
-        // issue every global gather before anything consumes one
-#pragma unroll
-        for (int u = 0; u < ACT_UNROLL; ++u) {
-            fd[u] = 0.0f;
-#pragma unroll
-            for (int c = 0; c < C; ++c) pv[u][c] = 0.0f;
-            if (vis[u]) {
-                if (C == 2) {
-                    const float2 t = *reinterpret_cast<const float2 *>(ph + (size_t)cell[u] * 2);
-                    pv[u][0] = t.x; pv[u][C - 1] = t.y;
-                } else {
-#pragma unroll
-                    for (int c = 0; c < C; ++c) pv[u][c] = ph[(size_t)cell[u] * C + c];
+            for (int u = 0; u < ACT_UNROLL; ++u) {
+                const int i = min(i0 + u, N - 1);
+                const bool real = (i0 + u < N) && lane < PP; // clamped duplicates must not count twice
+                const uint32_t cl = c_cell[u];
+                const uint32_t wd = cl >> 5, bit = 1u << (cl & 31);
+                if (real && explore && !(L.b_old[wd] & bit)) { // reward_custom.py:19,22 (mask ignored)
+                    atomicAdd(&L.cnt[i], 1u);
+                    atomicOr(&L.b_new[wd], bit);
                 }
-                fd[u] = food[cell[u]];
-            }
-        }
-        if (p.scaled) {
-#pragma unroll
-            for (int u = 0; u < ACT_UNROLL; ++u)
+                float pvs[C];
 #pragma unroll
                 for (int c = 0; c < C; ++c) {
-                    const float v = pv[u][c] * g_now;
-                    pv[u][c] = v < cut ? 0.0f : v;
+                    float v = c_pv[u][c];
+                    if (p.scaled) {
+                        v *= g_now;
+                        v = v < cut ? 0.0f : v;
+                    }
+                    pvs[c] = v * inv_max; // :124-125, reciprocal multiply (pheromone channels are held to 1e-5)
                 }
-        }
+                float *dst = obs_env + (size_t)i * row;
+                const uint32_t mis = (uint32_t)(((uintptr_t)dst >> 2) & 3);
+                float *o = stage + mis + qK;
+                const float v_ants = (L.b_pres[wd] & bit) ? 1.0f : 0.0f;  // :142
+                const float v_area = (area[wd] & bit) ? 1.0f : 0.0f;       // :130-131
+                const float v_wall = (walls[wd] & bit) ? 1.0f : 0.0f;      // :128-129
+                float v_rock = 0.0f;                                       // :132-135
+                if (LAYOUT != LAYOUT_DEFAULT && R > 0) {
+                    uint32_t rm = mask_q ? L.rockmask[i] : 0u;
+                    bool any = false;
+                    while (rm) {
+                        const int r = __builtin_ctz(rm);
+                        rm &= rm - 1;
+                        const double vx = (double)c_ix[u] - L.rock[3 * r + 0];
+                        const double vy = (double)c_iy[u] - L.rock[3 * r + 1];
+                        any |= sqrt(vx * vx + vy * vy) < L.rock[3 * r + 2];
+                    }
+                    v_rock = any ? 1.0f : 0.0f;
+                }
+                const bool m = mask_q; // RL_api.py:147-148: mask*(p+1)-1 == -1 on masked cells
+                if (LAYOUT == LAYOUT_DEFAULT || LAYOUT == LAYOUT_DEFAULT_ROCKS) {
+                    o[0] = m ? v_ants : -1.0f; o[1] = m ? pvs[0] : -1.0f; o[2] = m ? pvs[C - 1] : -1.0f;
+                    o[3] = m ? v_area : -1.0f; o[4] = m ? v_wall : -1.0f; o[5] = m ? c_fd[u] : -1.0f;
+                    if (LAYOUT == LAYOUT_DEFAULT_ROCKS) o[6] = m ? v_rock : -1.0f;
+                } else {
+                    for (int k = 0; k < K; ++k) {
+                        float v = 0.0f;
+                        switch (p.ch_kind[k]) {
+                        case ANTSRL_CH_PHERO: {
+                            float t = pvs[0];
 #pragma unroll
-        for (int u = 0; u < ACT_UNROLL; ++u) {
-            const uint32_t ubase = base + u * 64;
-            if (ubase >= total) break; // wave-uniform
-            if (valid[u]) {
-                const uint32_t cl = cell[u], i = ant[u];
-                if (explore && !test_bit(L.b_old, cl)) { // reward_custom.py:19,22 (mask ignored)
-                    atomicAdd(&L.cnt[i], 1u);
-                    atomicOr(&L.b_new[cl >> 5], 1u << (cl & 31));
-                }
-                if (obs_env) {
-                    float *o = stage + lane * K;
-                    if (!vis[u]) { // RL_api.py:147-148: mask*(p+1)-1 == -1
-                        for (int k = 0; k < K; ++k) o[k] = -1.0f;
-                    } else {
-                        const float v_ants = test_bit(L.b_pres, cl) ? 1.0f : 0.0f;  // :142
-                        const float v_area = test_bit(area, cl) ? 1.0f : 0.0f;       // :130-131
-                        const float v_wall = test_bit(walls, cl) ? 1.0f : 0.0f;      // :128-129
-                        float v_rock = 0.0f;                                         // :132-135
-                        if (LAYOUT != LAYOUT_DEFAULT && R > 0) {
-                            uint32_t rm = L.rockmask[i];
-                            bool any = false;
-                            while (rm) {
-                                const int r = __builtin_ctz(rm);
-                                rm &= rm - 1;
-                                const double vx = (double)ixv[u] - p.s.rock_cx[(size_t)e * R + r];
-                                const double vy = (double)iyv[u] - p.s.rock_cy[(size_t)e * R + r];
-                                any |= sqrt(vx * vx + vy * vy) < p.s.rock_r[(size_t)e * R + r];
-                            }
-                            v_rock = any ? 1.0f : 0.0f;
+                            for (int c = 1; c < C; ++c) t = (p.ch_arg[k] == c) ? pvs[c] : t;
+                            v = t;
+                        } break;
+                        case ANTSRL_CH_FOOD: v = c_fd[u]; break;      // :126-127
+                        case ANTSRL_CH_WALLS: v = v_wall; break;
+                        case ANTSRL_CH_ANTHILL: v = v_area; break;
+                        case ANTSRL_CH_ANTS: v = v_ants; break;
+                        case ANTSRL_CH_ROCKS: v = v_rock; break;
+                        default: break;
                         }
-                        if (LAYOUT == LAYOUT_DEFAULT || LAYOUT == LAYOUT_DEFAULT_ROCKS) {
-                            // phero/max_val (:124-125) as a multiply by the f32 reciprocal: the
-                            // pheromone channels are held to 1e-5, not bit-exactness (fp32 grid)
-                            o[0] = v_ants; o[1] = pv[u][0] * inv_max; o[2] = pv[u][C - 1] * inv_max;
-                            o[3] = v_area; o[4] = v_wall; o[5] = fd[u];
-                            if (LAYOUT == LAYOUT_DEFAULT_ROCKS) o[6] = v_rock;
-                        } else {
-                            for (int k = 0; k < K; ++k) {
-                                float v = 0.0f;
-                                switch (p.ch_kind[k]) {
-                                case ANTSRL_CH_PHERO: {
-                                    float t = pv[u][0];
+                        o[k] = m ? v : -1.0f;
+                    }
+                }
+                wave_lds_sync();
+                // copy the row out: two 16-byte stores per lane over the fully-inside float4s of the
+                // aligned window [mis, mis+row), one 4-byte store for the <= 6 edge floats; lanes
+                // with nothing left repeat a valid store (same address, same data)
+                float *dst_al = dst - mis;
+                const uint32_t j_lo = (mis + 3) >> 2, j_hi = (mis + row) >> 2; // interior float4s [j_lo, j_hi)
+                const uint32_t ja = min(j_lo + (uint32_t)lane, j_hi - 1), jb = min(j_lo + 64u + (uint32_t)lane, j_hi - 1);
+                const float4 va = reinterpret_cast<const float4 *>(stage)[ja];
+                const float4 vb = reinterpret_cast<const float4 *>(stage)[jb];
+                const uint32_t hd = 4 * j_lo - mis, tl = mis + row - 4 * j_hi;
+                const uint32_t fe = (uint32_t)lane < hd ? mis + lane
+                                    : ((uint32_t)lane - hd < tl ? 4 * j_hi + ((uint32_t)lane - hd) : mis);
+                const float ve = stage[fe];
+                reinterpret_cast<float4 *>(dst_al)[ja] = va;
+                reinterpret_cast<float4 *>(dst_al)[jb] = vb;
+                dst_al[fe] = ve;
+                wave_lds_sync();
+            }
 #pragma unroll
-                                    for (int c = 1; c < C; ++c) t = (p.ch_arg[k] == c) ? pv[u][c] : t;
-                                    v = t * inv_max;
-                                } break;
-                                case ANTSRL_CH_FOOD: v = fd[u]; break;      // :126-127
-                                case ANTSRL_CH_WALLS: v = v_wall; break;
-                                case ANTSRL_CH_ANTHILL: v = v_area; break;
-                                case ANTSRL_CH_ANTS: v = v_ants; break;
-                                case ANTSRL_CH_ROCKS: v = v_rock; break;
-                                default: break;
-                                }
-                                o[k] = v;
+            for (int u = 0; u < ACT_UNROLL; ++u) {
+                c_cell[u] = n_cell[u]; c_ix[u] = n_ix[u]; c_iy[u] = n_iy[u]; c_fd[u] = n_fd[u];
+#pragma unroll
+                for (int c = 0; c < C; ++c) c_pv[u][c] = n_pv[u][c];
+            }
+        }
+#undef ACT_FETCH
+    }
+    if (!FAST)
+    for (int i0 = wave * ACT_UNROLL; i0 < ((flags & ACT_ABL_NO_ITEMS) ? 0 : N); i0 += nwaves * ACT_UNROLL) {
+        for (int pass = 0; pass < npass; ++pass) {
+            const int q = pass * 64 + lane;
+            const bool lane_on = q < PP;
+            const CellOff of = L.off[lane_on ? q : 0];
+            const bool mask_q = lane_on && L.t_mask[lane_on ? q : 0];
+            uint32_t cell[ACT_UNROLL];
+            int ixv[ACT_UNROLL], iyv[ACT_UNROLL];
+            bool valid[ACT_UNROLL], vis[ACT_UNROLL];
+            float pv[ACT_UNROLL][C];
+            float fd[ACT_UNROLL];
+#pragma unroll
+            for (int u = 0; u < ACT_UNROLL; ++u) {
+                const int i = i0 + u;
+                valid[u] = lane_on && i < N;
+                const AntFrame fr = L.frame[i < N ? i : 0]; // wave-uniform address: LDS broadcast
+                const double rx = fr.ct * of.px - fr.st * of.py; // RL_api.py:110-111
+                const double ry = fr.st * of.px + fr.ct * of.py;
+                int ix = (int)rint(rx + fr.cx), iy = (int)rint(ry + fr.cy); // :114-117 (half to even)
+                if (wrap_fast) {                                             // :118-119
+                    ix += ix < 0 ? W : 0; ix -= ix >= W ? W : 0;
+                    iy += iy < 0 ? H : 0; iy -= iy >= H ? H : 0;
+                } else {
+                    ix = wrap_index(ix, W); iy = wrap_index(iy, H);
+                }
+                ixv[u] = ix; iyv[u] = iy;
+                cell[u] = (uint32_t)(ix * H + iy);
+                vis[u] = valid[u] && mask_q && obs_env;
+            }
+            // issue every global gather before anything consumes one
+#pragma unroll
+            for (int u = 0; u < ACT_UNROLL; ++u) {
+                fd[u] = 0.0f;
+#pragma unroll
+                for (int c = 0; c < C; ++c) pv[u][c] = 0.0f;
+                if (vis[u] && !abl_gather) {
+                    if (C == 2) {
+                        const float2 t = *reinterpret_cast<const float2 *>(ph + (size_t)cell[u] * 2);
+                        pv[u][0] = t.x; pv[u][C - 1] = t.y;
+                    } else {
+#pragma unroll
+                        for (int c = 0; c < C; ++c) pv[u][c] = ph[(size_t)cell[u] * C + c];
+                    }
+                    fd[u] = food[cell[u]];
+                }
+            }
+            if (p.scaled) {
+#pragma unroll
+                for (int u = 0; u < ACT_UNROLL; ++u)
+#pragma unroll
+                    for (int c = 0; c < C; ++c) {
+                        const float v = pv[u][c] * g_now;
+                        pv[u][c] = v < cut ? 0.0f : v;
+                    }
+            }
+#pragma unroll
+            for (int u = 0; u < ACT_UNROLL; ++u) {
+                const int i = i0 + u;
+                if (i >= N) break; // wave-uniform
+                const uint32_t cl = cell[u];
+                const uint32_t wd = cl >> 5, bit = 1u << (cl & 31);
+                if (valid[u] && explore && !abl_explore && !(L.b_old[wd] & bit)) { // reward_custom.py:19,22
+                    atomicAdd(&L.cnt[i], 1u);                                       // (mask ignored)
+                    atomicOr(&L.b_new[wd], bit);
+                }
+                if (!obs_env) continue;
+                // destination row of this ant; the staging image is shifted by the row's misalignment
+                // so that 16-byte LDS reads line up with 16-byte global stores
+                float *dst = obs_env + (size_t)i * row;
+                const uint32_t mis = (uint32_t)(((uintptr_t)dst >> 2) & 3);
+                if (valid[u]) {
+                    float *o = stage + mis + (uint32_t)q * K;
+                    const float v_ants = (L.b_pres[wd] & bit) ? 1.0f : 0.0f;  // :142
+                    const float v_area = (area[wd] & bit) ? 1.0f : 0.0f;       // :130-131
+                    const float v_wall = (walls[wd] & bit) ? 1.0f : 0.0f;      // :128-129
+                    float v_rock = 0.0f;                                       // :132-135
+                    if (LAYOUT != LAYOUT_DEFAULT && R > 0) {
+                        uint32_t rm = vis[u] ? L.rockmask[i] : 0u;
+                        bool any = false;
+                        while (rm) {
+                            const int r = __builtin_ctz(rm);
+                            rm &= rm - 1;
+                            const double vx = (double)ixv[u] - L.rock[3 * r + 0];
+                            const double vy = (double)iyv[u] - L.rock[3 * r + 1];
+                            any |= sqrt(vx * vx + vy * vy) < L.rock[3 * r + 2];
+                        }
+                        v_rock = any ? 1.0f : 0.0f;
+                    }
+                    const bool m = vis[u]; // RL_api.py:147-148: mask*(p+1)-1 == -1 on masked cells
+                    if (LAYOUT == LAYOUT_DEFAULT || LAYOUT == LAYOUT_DEFAULT_ROCKS) {
+                        // phero/max_val (:124-125) as a multiply by the f32 reciprocal: the
+                        // pheromone channels are held to 1e-5, not bit-exactness (fp32 grid)
+                        o[0] = m ? v_ants : -1.0f; o[1] = m ? pv[u][0] * inv_max : -1.0f;
+                        o[2] = m ? pv[u][C - 1] * inv_max : -1.0f;
+                        o[3] = m ? v_area : -1.0f; o[4] = m ? v_wall : -1.0f; o[5] = m ? fd[u] : -1.0f;
+                        if (LAYOUT == LAYOUT_DEFAULT_ROCKS) o[6] = m ? v_rock : -1.0f;
+                    } else {
+                        for (int k = 0; k < K; ++k) {
+                            float v = 0.0f;
+                            switch (p.ch_kind[k]) {
+                            case ANTSRL_CH_PHERO: {
+                                float t = pv[u][0];
+#pragma unroll
+                                for (int c = 1; c < C; ++c) t = (p.ch_arg[k] == c) ? pv[u][c] : t;
+                                v = t * inv_max;
+                            } break;
+                            case ANTSRL_CH_FOOD: v = fd[u]; break;      // :126-127
+                            case ANTSRL_CH_WALLS: v = v_wall; break;
+                            case ANTSRL_CH_ANTHILL: v = v_area; break;
+                            case ANTSRL_CH_ANTS: v = v_ants; break;
+                            case ANTSRL_CH_ROCKS: v = v_rock; break;
+                            default: break;
                             }
+                            o[k] = m ? v : -1.0f;
                         }
                     }
                 }
-            }
-            if (obs_env) {
-                wave_lds_sync();
-                const uint32_t nvalid = min(64u, total - ubase);
-                const uint32_t nfl = nvalid * (uint32_t)K;
-                float *dst = obs_env + (size_t)ubase * K;
-                if (vec_ok) { // ubase*K*4 is a multiple of 256 bytes; env base is 16-byte aligned
-                    const uint32_t n4 = nfl >> 2;
-                    for (uint32_t j = lane; j < n4; j += 64)
-                        reinterpret_cast<float4 *>(dst)[j] = reinterpret_cast<const float4 *>(stage)[j];
-                    for (uint32_t j = (n4 << 2) + lane; j < nfl; j += 64) dst[j] = stage[j];
-                } else {
-                    for (uint32_t j = lane; j < nfl; j += 64) dst[j] = stage[j];
+                if (pass == npass - 1) { // the ant's row is complete: copy it out
+                    wave_lds_sync();
+                    if (!abl_store) {
+                        float *dst_al = dst - mis; // 16-byte aligned window [mis, mis + row)
+                        const uint32_t n4 = (mis + row + 3) >> 2;
+                        for (uint32_t j = lane; j < n4; j += 64) {
+                            const float4 v = reinterpret_cast<const float4 *>(stage)[j];
+                            const uint32_t lo = 4 * j;
+                            if (lo >= mis && lo + 3 < mis + row) {
+                                reinterpret_cast<float4 *>(dst_al)[j] = v;
+                            } else {
+                                if (lo + 0 >= mis && lo + 0 < mis + row) dst_al[lo + 0] = v.x;
+                                if (lo + 1 >= mis && lo + 1 < mis + row) dst_al[lo + 1] = v.y;
+                                if (lo + 2 >= mis && lo + 2 < mis + row) dst_al[lo + 2] = v.z;
+                                if (lo + 3 >= mis && lo + 3 < mis + row) dst_al[lo + 3] = v.w;
+                            }
+                        }
+                    }
+                    wave_lds_sync();
                 }
-                wave_lds_sync();
             }
         }
     }
@@ -508,6 +697,12 @@ k_act(const KP p, const int8_t *__restrict__ rotation, const int8_t *__restrict_
         if (p.reward_kind != ANTSRL_REWARD_NONE) p.s.reward_primed[e] = 1;
         if (do_step && done) done[e] = (uint8_t)(p.max_time == p.s.timestep[e]); // RL_api.py:200
     }
+    if (flags & ACT_FUSED_UPDATE) {
+        // Environment.update of the same step (main.py:131) in the same launch: the staging
+        // region is dead after phase 3 and doubles as the update's scratch.
+        __syncthreads();
+        update_env<C>(p, e, wall_jitter, out_buf, (unsigned char *)L.hkeys);
+    }
 }
 
 // ===================================================================================
@@ -534,12 +729,13 @@ __device__ __forceinline__ uint32_t block_excl_scan_flag(bool flag, uint32_t *wa
     return off + in_wave;
 }
 
+// The update phases of ONE environment, run by the whole workgroup.  `smem` is
+// update_scratch_bytes() of LDS.  Called by k_update and, fused, at the tail of k_act.
 template <int C>
-__global__ void __launch_bounds__(1024)
-k_update(const KP p, const double *__restrict__ wall_jitter, const int out_buf)
+__device__ __forceinline__ void update_env(const KP &p, const int e, const double *__restrict__ wall_jitter,
+                                           const int out_buf, unsigned char *smem)
 {
-    extern __shared__ __align__(16) unsigned char smem[];
-    const int e = blockIdx.x, tid = threadIdx.x, T = blockDim.x;
+    const int tid = threadIdx.x, T = blockDim.x;
     const int lane = tid & 63, wave = tid >> 6, nwaves = T >> 6;
     const int N = p.N, W = p.W, H = p.H, R = p.R;
     const size_t G = (size_t)W * H, eN = (size_t)e * N;
@@ -715,6 +911,14 @@ k_update(const KP p, const double *__restrict__ wall_jitter, const int out_buf)
         if (s != 0.0) p.s.anthill_food[e] += s;
         p.s.timestep[e] = ts;
     }
+}
+
+template <int C>
+__global__ void __launch_bounds__(1024)
+k_update(const KP p, const double *__restrict__ wall_jitter, const int out_buf)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    update_env<C>(p, blockIdx.x, wall_jitter, out_buf, smem);
 }
 
 // Anthill.update over the WHOLE grid (anthill.py:41-46): needed on the first update after a
@@ -1055,17 +1259,13 @@ static ActPlan plan_act(const KP &p)
     for (const auto &c : cand) {
         pl.threads = c.threads;
         pl.static_lds = c.st;
-        pl.lds = act_lds_bytes(p.N, p.PP, p.words, p.HT, p.K, c.threads / 64, c.st, nullptr, nullptr);
+        pl.lds = act_lds_bytes(p.N, p.PP, p.words, p.HT, p.K, c.threads / 64, c.st, nullptr, nullptr, p.R);
         if (pl.lds <= c.limit) return pl;
     }
     return pl; // caller checks pl.lds <= cap
 }
 
-static size_t update_lds_bytes(const KP &p, int threads)
-{
-    return align_up(8 * (size_t)p.HT, 16) + 16 * (size_t)(p.R > 0 ? p.R : 1) + 8 * (size_t)(threads / 64) +
-           4 * (size_t)(threads / 64) + 16;
-}
+static size_t update_lds_bytes(const KP &p, int threads) { return update_scratch_bytes(p.HT, p.R, threads / 64); }
 
 static int act_layout(const KP &p)
 {
@@ -1078,46 +1278,62 @@ static int act_layout(const KP &p)
     return p.K == 6 ? LAYOUT_DEFAULT : LAYOUT_DEFAULT_ROCKS;
 }
 
-template <int C, bool ST, int LAYOUT>
+template <int C, bool ST, int LAYOUT, bool FAST>
 static hipError_t launch_act_k(const KP &p, const ActPlan &pl, const int8_t *rot, const int8_t *ph, int cur,
                                float *obs, float *agent_state, float *reward, uint8_t *done, int flags,
-                               hipStream_t st)
+                               const double *jitter, int out_buf, hipStream_t st)
 {
     static size_t attr_lds = 0; // dynamic-LDS opt-in is per kernel function, set once per size
     if (pl.lds > attr_lds) {
-        hipError_t err = hipFuncSetAttribute((const void *)k_act<C, ST, LAYOUT>,
+        hipError_t err = hipFuncSetAttribute((const void *)k_act<C, ST, LAYOUT, FAST>,
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds);
         if (err != hipSuccess) return err;
         attr_lds = pl.lds;
     }
-    hipLaunchKernelGGL((k_act<C, ST, LAYOUT>), dim3(p.E), dim3(pl.threads), pl.lds, st, p, rot, ph, cur, obs,
-                       agent_state, reward, done, flags);
+    hipLaunchKernelGGL((k_act<C, ST, LAYOUT, FAST>), dim3(p.E), dim3(pl.threads), pl.lds, st, p, rot, ph, cur, obs,
+                       agent_state, reward, done, flags, jitter, out_buf);
     return hipGetLastError();
 }
 
 template <int C>
 static hipError_t launch_act_c(const KP &p, const int8_t *rot, const int8_t *ph, int cur, float *obs,
-                               float *agent_state, float *reward, uint8_t *done, int flags, hipStream_t st)
+                               float *agent_state, float *reward, uint8_t *done, int flags,
+                               const double *jitter, int out_buf, hipStream_t st)
 {
     const ActPlan pl = plan_act(p);
     if (pl.lds > 160 * 1024) return hipErrorInvalidValue;
     const int layout = (C == 2) ? act_layout(p) : LAYOUT_GENERIC;
-#define ACT_GO(ST, LY) return launch_act_k<C, ST, LY>(p, pl, rot, ph, cur, obs, agent_state, reward, done, flags, st)
-    if (C == 2 && layout == LAYOUT_DEFAULT) { if (pl.static_lds) ACT_GO(true, (C == 2 ? LAYOUT_DEFAULT : LAYOUT_GENERIC)); else ACT_GO(false, (C == 2 ? LAYOUT_DEFAULT : LAYOUT_GENERIC)); }
-    if (C == 2 && layout == LAYOUT_DEFAULT_ROCKS) { if (pl.static_lds) ACT_GO(true, (C == 2 ? LAYOUT_DEFAULT_ROCKS : LAYOUT_GENERIC)); else ACT_GO(false, (C == 2 ? LAYOUT_DEFAULT_ROCKS : LAYOUT_GENERIC)); }
-    if (pl.static_lds) ACT_GO(true, LAYOUT_GENERIC);
-    ACT_GO(false, LAYOUT_GENERIC);
+    const uint32_t row = (uint32_t)p.PP * p.K;
+    // the pipelined loop: one pass (PP <= 64), row of 8..508 floats, observation wanted, no ablation
+    const bool fast = C == 2 && layout != LAYOUT_GENERIC && p.PP <= 64 && row >= 8 && row <= 508 && obs &&
+                      !(flags & 0xF00);
+#define ACT_GO(ST, LY, FA) \
+    return launch_act_k<C, ST, LY, FA>(p, pl, rot, ph, cur, obs, agent_state, reward, done, flags, jitter, out_buf, st)
+    if (C == 2 && layout != LAYOUT_GENERIC) {
+        constexpr int LD = C == 2 ? LAYOUT_DEFAULT : LAYOUT_GENERIC, LR = C == 2 ? LAYOUT_DEFAULT_ROCKS : LAYOUT_GENERIC;
+        constexpr bool F = C == 2;
+        if (layout == LAYOUT_DEFAULT) {
+            if (fast) { if (pl.static_lds) ACT_GO(true, LD, F); else ACT_GO(false, LD, F); }
+            if (pl.static_lds) ACT_GO(true, LD, false); else ACT_GO(false, LD, false);
+        } else {
+            if (fast) { if (pl.static_lds) ACT_GO(true, LR, F); else ACT_GO(false, LR, F); }
+            if (pl.static_lds) ACT_GO(true, LR, false); else ACT_GO(false, LR, false);
+        }
+    }
+    if (pl.static_lds) ACT_GO(true, LAYOUT_GENERIC, false);
+    ACT_GO(false, LAYOUT_GENERIC, false);
 #undef ACT_GO
 }
 
 hipError_t antsrl_launch_act(const KP &p, const int8_t *rot, const int8_t *ph, int cur, float *obs,
-                             float *agent_state, float *reward, uint8_t *done, int flags, hipStream_t st)
+                             float *agent_state, float *reward, uint8_t *done, int flags,
+                             const double *jitter, int out_buf, hipStream_t st)
 {
     switch (p.C) {
-    case 1: return launch_act_c<1>(p, rot, ph, cur, obs, agent_state, reward, done, flags, st);
-    case 2: return launch_act_c<2>(p, rot, ph, cur, obs, agent_state, reward, done, flags, st);
-    case 3: return launch_act_c<3>(p, rot, ph, cur, obs, agent_state, reward, done, flags, st);
-    case 4: return launch_act_c<4>(p, rot, ph, cur, obs, agent_state, reward, done, flags, st);
+    case 1: return launch_act_c<1>(p, rot, ph, cur, obs, agent_state, reward, done, flags, jitter, out_buf, st);
+    case 2: return launch_act_c<2>(p, rot, ph, cur, obs, agent_state, reward, done, flags, jitter, out_buf, st);
+    case 3: return launch_act_c<3>(p, rot, ph, cur, obs, agent_state, reward, done, flags, jitter, out_buf, st);
+    case 4: return launch_act_c<4>(p, rot, ph, cur, obs, agent_state, reward, done, flags, jitter, out_buf, st);
     default: return hipErrorInvalidValue;
     }
 }
