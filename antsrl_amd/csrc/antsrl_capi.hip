@@ -165,6 +165,16 @@ static void fill_kp(const AntsCfg *c, KP *p)
     p->fct_explore = c->fct_explore; p->fct_food = c->fct_food; p->fct_anthill = c->fct_anthill;
     p->fct_explore_holding = c->fct_explore_holding; p->fct_heading = c->fct_headinganthill;
     memcpy(p->filter, c->filter, sizeof(p->filter));
+    {
+        const int S = 2 * c->filter_radius + 1;
+        for (int a = 0; a < S; ++a)
+            for (int b = 0; b < S; ++b) {
+                const double f = c->filter[a * S + b];
+                const float hi = (float)f;
+                p->ftap[(b * S + a) * 2 + 0] = hi;
+                p->ftap[(b * S + a) * 2 + 1] = (float)(f - (double)hi);
+            }
+    }
     p->rng_seed = c->rng_seed;
     p->scaled = use_scaled(c) ? 1 : 0;
     p->g_now = p->g_dep = p->inv_g_dep = 1.0;

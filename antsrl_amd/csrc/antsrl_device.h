@@ -55,6 +55,10 @@ struct KP {
     double g_now;     // f0^S          : materialises values for the perception gather / read-out
     double g_dep;     // f0^(S+1)      : at deposit time, after the conceptual sweep of this update
     double inv_g_dep; // 1 / g_dep
+    // DIFFUSE_FILTER taps split into fp32 hi + lo (hi + lo == the float64 tap to ~1e-15): the
+    // stencil runs in fp32 FMAs without the systematic per-step bias a rounded tap would add
+    // layout [b][a]{hi,lo} (b = tap column, a = tap row) so one column's taps are contiguous
+    float ftap[2 * ANTSRL_MAX_FILTER_TAPS];
 };
 
 // k_act flags

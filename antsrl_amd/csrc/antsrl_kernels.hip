@@ -13,6 +13,7 @@
 // Reference citations are relative to the reference checkout (environment/...).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "antsrl_device.h"
 
 #define WAVE 64
@@ -1091,6 +1092,147 @@ __global__ void __launch_bounds__(256) k_phero_renorm(const KP p)
     }
 }
 
+// Radius 1..3, main kernel: register-marching stencil.  One wave owns a strip of 64-2R output
+// columns (lane <-> column y, R halo lanes each side) of one environment and marches down the
+// x rows in blocks of S = 2R+1 rows: every input row is read ONCE, coalesced, straight into
+// registers (all S rows of a block are in flight together, no branch between them); its 2R
+// y-neighbours come from the other lanes of the wave (__shfl); the 2S-1 output rows a block
+// touches are running accumulators in registers.  No LDS, no re-reads except the 2R halo columns.
+//   out[x,y] = sum_{a,b} F[a,b] * in[x-a+R, y-b+R]      (convolve2d 'same', zero fill)
+// Arithmetic: fp32 FMAs with the taps split hi+lo (see KP::ftap) — unbiased to ~1e-15 per step.
+// Loop order b -> a -> row keeps only one tap column (2S scalars) live at a time.
+template <int C, int R>
+__global__ void __launch_bounds__(256)
+k_sweep_march(const KP p, const float *__restrict__ in, float *__restrict__ out, const int seg_rows)
+{
+    constexpr int S = 2 * R + 1, OUTW = 64 - 2 * R, NA = 2 * S - 1;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int e = blockIdx.y, W = p.W, H = p.H;
+    const int strip = blockIdx.x * 4 + wave;
+    // The S*S taps {hi, lo} sit in LDS and are read back (uniform address = broadcast) right where
+    // they are used: ~100 wave-uniform scalars do not fit the SGPR file — as kernel arguments the
+    // compiler hoists them out of the march and spills them through v_writelane/v_readlane.
+    __shared__ float taps[2 * ANTSRL_MAX_FILTER_TAPS];
+    if (threadIdx.x < 2 * S * S) taps[threadIdx.x] = p.ftap[threadIdx.x];
+    __syncthreads();
+    if (strip * OUTW >= H) return; // whole wave (no further barriers)
+    const int y = strip * OUTW - R + lane;
+    const bool col_in = y >= 0 && y < H;
+    const bool col_out = lane >= R && lane < 64 - R && y < H;
+    const int yc = col_in ? y : 0;
+    const float colmask = col_in ? 1.0f : 0.0f;
+    const size_t G = (size_t)W * H;
+    const float *src = in + (size_t)e * G * C;
+    float *dst = out + (size_t)e * G * C;
+    const uint32_t *walls = p.s.walls_bits + (size_t)e * p.words;
+    const bool clip = p.has_max_val && p.N > 0;
+    const float thr = (float)p.threshold, mx = (float)p.max_val;
+    // acc[j] accumulates output row x = xi0 - R + j of the current block
+    float acc[NA][C];
+#pragma unroll
+    for (int j = 0; j < NA; ++j)
+#pragma unroll
+        for (int c = 0; c < C; ++c) acc[j][c] = 0.0f;
+
+    // This wave produces output rows [x_lo, x_hi): it marches input rows x_lo - R .. x_hi - 1 + R
+    // (rows outside the grid count as zero), i.e. 2R rows of overlap with its x-neighbour segment.
+    const int x_lo = blockIdx.z * seg_rows, x_hi = min(x_lo + seg_rows, W);
+    // one block of S rows is always in flight ahead of the block being accumulated
+    float nv[S][C];
+    uint32_t nword[S], ncell[S];
+#define MARCH_LOAD(XI0)                                                                              \
+    {                                                                                                \
+        _Pragma("unroll") for (int s = 0; s < S; ++s)                                                \
+        {                                                                                            \
+            const int xc = min(max((XI0) + s, 0), W - 1); /* clamped; masked to zero below */        \
+            ncell[s] = (uint32_t)(xc * H + yc);                                                      \
+            nword[s] = walls[ncell[s] >> 5];                                                         \
+        }                                                                                            \
+        _Pragma("unroll") for (int s = 0; s < S; ++s)                                                \
+        {                                                                                            \
+            if (C == 2) {                                                                            \
+                const float2 t = *reinterpret_cast<const float2 *>(src + (size_t)ncell[s] * 2);      \
+                nv[s][0] = t.x; nv[s][C - 1] = t.y;                                                  \
+            } else {                                                                                 \
+                _Pragma("unroll") for (int c = 0; c < C; ++c) nv[s][c] = src[(size_t)ncell[s] * C + c]; \
+            }                                                                                        \
+        }                                                                                            \
+    }
+    MARCH_LOAD(x_lo - R)
+    for (int xi0 = x_lo - R; xi0 < x_hi + R; xi0 += S) {
+        float v[S][C];
+        uint32_t wword[S];
+        uint32_t cellv[S];
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            cellv[s] = ncell[s]; wword[s] = nword[s];
+#pragma unroll
+            for (int c = 0; c < C; ++c) v[s][c] = nv[s][c];
+        }
+        MARCH_LOAD(xi0 + S) // prefetch (clamped addresses: a harmless re-read past the end)
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            // zero fill outside the grid, and walls.py:30 zeroes the INPUT of the convolution.
+            // Arithmetic masks (0/1 factors) rather than selects: lane-mask booleans would each
+            // occupy an SGPR pair and spill.
+            const float keep = colmask * (float)(1u - ((wword[s] >> (cellv[s] & 31)) & 1u)) *
+                               ((xi0 + s >= 0 && xi0 + s < W) ? 1.0f : 0.0f);
+#pragma unroll
+            for (int c = 0; c < C; ++c) v[s][c] *= keep;
+        }
+        // ---- accumulate: input row s feeds output row j = s + a (x = xi0 + s + a - R).
+        //      The tap-column loop is a REAL loop (not unrolled): only one column's 2S taps are live,
+        //      so nothing tempts the compiler to hoist ~100 scalars out of the march and spill them.
+#pragma unroll 1
+        for (int b = 0; b < S; ++b) {
+            float sh[S][C]; // sh[s] = in[xi0+s][y - b + R]
+#pragma unroll
+            for (int s = 0; s < S; ++s)
+#pragma unroll
+                for (int c = 0; c < C; ++c) sh[s][c] = __shfl(v[s][c], lane - (b - R));
+            const float *tp = taps + 2 * b * S;
+#pragma unroll
+            for (int a = 0; a < S; ++a) {
+                const float fh = tp[2 * a], fl = tp[2 * a + 1]; // LDS, uniform address: broadcast
+#pragma unroll
+                for (int s = 0; s < S; ++s)
+#pragma unroll
+                    for (int c = 0; c < C; ++c) {
+                        acc[s + a][c] = fmaf(fh, sh[s][c], acc[s + a][c]);
+                        acc[s + a][c] = fmaf(fl, sh[s][c], acc[s + a][c]);
+                    }
+            }
+        }
+        // ---- rows j = 0..S-1 are complete (last contributor: input row xi0 + j, tap row 0)
+#pragma unroll
+        for (int j = 0; j < S; ++j) {
+            const int x = xi0 - R + j;
+            if (x >= x_lo && x < x_hi && col_out) {
+                float r[C];
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    float f = acc[j][c] < thr ? 0.0f : acc[j][c]; // pheromone.py:45
+                    if (clip) f = fminf(f, mx);
+                    r[c] = f;
+                }
+                const size_t o = ((size_t)x * H + y) * C;
+                if (C == 2) {
+                    *reinterpret_cast<float2 *>(dst + o) = make_float2(r[0], r[C - 1]);
+                } else {
+#pragma unroll
+                    for (int c = 0; c < C; ++c) dst[o + c] = r[c];
+                }
+            }
+        }
+        // carry the S-1 partial rows over to the next block
+#pragma unroll
+        for (int j = 0; j < NA; ++j)
+#pragma unroll
+            for (int c = 0; c < C; ++c) acc[j][c] = (j + S < NA) ? acc[j + S][c] : 0.0f;
+    }
+#undef MARCH_LOAD
+}
+
 // ===================================================================================
 // reset / state I/O (not on the hot path)
 // ===================================================================================
@@ -1356,7 +1498,19 @@ static hipError_t launch_sweep_c(const KP &p, int cur, hipStream_t st)
             if (blocks > 256 * 64) blocks = 256 * 64;
             hipLaunchKernelGGL((k_sweep0_scalar<C>), dim3((unsigned)blocks), dim3(256), 0, st, p, in, out, n);
         }
-    } else {
+    } else if (!getenv("ANTSRL_SWEEP_TILED")) {
+        const int fr = p.filter_radius;
+        const int strips = (p.H + (64 - 2 * fr) - 1) / (64 - 2 * fr);
+        // split the march along x into segments of >= 64 rows until the chip has ~16 waves per SIMD
+        // to choose from (each extra segment re-reads 2R rows)
+        int nseg = 1;
+        while ((long long)p.E * strips * nseg < 16 * 1024 && p.W / (nseg * 2) >= 64) nseg *= 2;
+        const int seg_rows = (p.W + nseg - 1) / nseg;
+        dim3 grid((strips + 3) / 4, p.E, (p.W + seg_rows - 1) / seg_rows);
+        if (fr == 1) hipLaunchKernelGGL((k_sweep_march<C, 1>), grid, dim3(256), 0, st, p, in, out, seg_rows);
+        else if (fr == 2) hipLaunchKernelGGL((k_sweep_march<C, 2>), grid, dim3(256), 0, st, p, in, out, seg_rows);
+        else hipLaunchKernelGGL((k_sweep_march<C, 3>), grid, dim3(256), 0, st, p, in, out, seg_rows);
+    } else { // LDS-tiled float64 reference variant (A/B and cross-check: ANTSRL_SWEEP_TILED=1)
         const int fr = p.filter_radius;
         const size_t lds = (size_t)(SW_TX + 2 * fr) * (SW_TY + 2 * fr) * C * sizeof(float);
         dim3 grid((p.H + SW_TY - 1) / SW_TY, (p.W + SW_TX - 1) / SW_TX, p.E);
