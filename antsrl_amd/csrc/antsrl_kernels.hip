@@ -139,7 +139,7 @@ struct ActLds {
     CellOff *off;                      // [PP]
     uint32_t *cnt;                     // [N] unexplored-cell count / temp cell index
     uint32_t *rockmask;                // [N] rocks that can touch the ant's patch
-    uint32_t *b_pres, *b_old, *b_new;  // [words] presence / explored (pre-step) / explored (marked)
+    uint32_t *b_pres, *b_old;          // [words] presence / explored map as it was before this step
     uint32_t *b_walls, *b_area;        // [words] (only when STATIC_LDS)
     uint8_t *t_mask;                   // [PP]
     double *rock;                      // [3R] cx, cy, radius of this env's rocks
@@ -163,7 +163,7 @@ __host__ __device__ __forceinline__ size_t act_lds_bytes(int N, int PP, int word
     size_t a_fr = take(sizeof(AntFrame) * (size_t)N);
     size_t a_off = take(sizeof(CellOff) * (size_t)PP);
     size_t a_cnt = take(4 * (size_t)N), a_rm = take(4 * (size_t)N);
-    size_t a_pres = take(4 * (size_t)words), a_old = take(4 * (size_t)words), a_new = take(4 * (size_t)words);
+    size_t a_pres = take(4 * (size_t)words), a_old = take(4 * (size_t)words);
     size_t a_w = 0, a_a = 0;
     if (static_lds) {
         a_w = take(4 * (size_t)words);
@@ -179,7 +179,6 @@ __host__ __device__ __forceinline__ size_t act_lds_bytes(int N, int PP, int word
         o->off = (CellOff *)(base + a_off);
         o->cnt = (uint32_t *)(base + a_cnt); o->rockmask = (uint32_t *)(base + a_rm);
         o->b_pres = (uint32_t *)(base + a_pres); o->b_old = (uint32_t *)(base + a_old);
-        o->b_new = (uint32_t *)(base + a_new);
         o->b_walls = (uint32_t *)(base + a_w); o->b_area = (uint32_t *)(base + a_a);
         o->t_mask = base + a_mask;
         o->rock = (double *)(base + a_rock);
@@ -199,8 +198,10 @@ __host__ __device__ __forceinline__ size_t act_lds_bytes(int N, int PP, int word
 // FAST selects the software-pipelined perception loop (see phase 3); the two loops live in
 // separate instantiations on purpose: with both in one kernel the optimiser stops scalarising the
 // LDS carve (`ActLds`), its pointers go through scratch and every LDS access degrades to flat_*.
-template <int C, bool STATIC_LDS, int LAYOUT, bool FAST>
-__global__ void __launch_bounds__(1024)
+// TPB = threads per workgroup (512 or 1024); 4 waves per SIMD (<= 128 VGPRs) is all the LDS plans
+// can use (capping at 80 VGPRs for a third workgroup per CU measured slower, see plan_act).
+template <int C, bool STATIC_LDS, int LAYOUT, bool FAST, int TPB>
+__global__ void __launch_bounds__(TPB, 4)
 k_act(const KP p, const int8_t *__restrict__ rotation, const int8_t *__restrict__ phero_act, const int cur,
       float *__restrict__ obs, float *__restrict__ agent_state, float *__restrict__ reward,
       uint8_t *__restrict__ done, const int flags, const double *__restrict__ wall_jitter, const int out_buf)
@@ -227,10 +228,8 @@ k_act(const KP p, const int8_t *__restrict__ rotation, const int8_t *__restrict_
 
     // ---- phase 0: stage bitmaps and tables in LDS
     for (int w = tid; w < p.words; w += T) {
-        uint32_t ex = g_expl[w];
         L.b_pres[w] = 0u;
-        L.b_old[w] = ex;
-        L.b_new[w] = ex;
+        L.b_old[w] = g_expl[w];
         if (STATIC_LDS) {
             L.b_walls[w] = g_walls[w];
             L.b_area[w] = g_area[w];
@@ -428,7 +427,7 @@ k_act(const KP p, const int8_t *__restrict__ rotation, const int8_t *__restrict_
                 const uint32_t wd = cl >> 5, bit = 1u << (cl & 31);
                 if (real && explore && !(L.b_old[wd] & bit)) { // reward_custom.py:19,22 (mask ignored)
                     atomicAdd(&L.cnt[i], 1u);
-                    atomicOr(&L.b_new[wd], bit);
+                    atomicOr(&g_expl[wd], bit); // marks go straight to HBM: every count uses the LDS copy of the pre-step map
                 }
                 float pvs[C];
 #pragma unroll
@@ -575,7 +574,7 @@ k_act(const KP p, const int8_t *__restrict__ rotation, const int8_t *__restrict_
                 const uint32_t wd = cl >> 5, bit = 1u << (cl & 31);
                 if (valid[u] && explore && !abl_explore && !(L.b_old[wd] & bit)) { // reward_custom.py:19,22
                     atomicAdd(&L.cnt[i], 1u);                                       // (mask ignored)
-                    atomicOr(&L.b_new[wd], bit);
+                    atomicOr(&g_expl[wd], bit); // marks go straight to HBM: every count uses the LDS copy of the pre-step map
                 }
                 if (!obs_env) continue;
                 // destination row of this ant; the staging image is shifted by the row's misalignment
@@ -692,8 +691,6 @@ k_act(const KP p, const int8_t *__restrict__ rotation, const int8_t *__restrict_
         if (reward) reward[eN + i] = (float)rw;
         if (do_step && rw - p.reward_threshold > 0) p.s.reward_state[eN + i] = 255; // ants.py:119-121
     }
-    if (explore)
-        for (int w = tid; w < p.words; w += T) g_expl[w] = L.b_new[w];
     if (tid == 0) {
         if (p.reward_kind != ANTSRL_REWARD_NONE) p.s.reward_primed[e] = 1;
         if (do_step && done) done[e] = (uint8_t)(p.max_time == p.s.timestep[e]); // RL_api.py:200
@@ -1377,7 +1374,7 @@ __global__ void k_read_state(const KP p, const int which, const int cur, void *_
 // ===================================================================================
 // host-side launchers (called from antsrl_capi.hip)
 // ===================================================================================
-static inline int pick_act_threads(int N) { return N <= 256 ? 256 : 512; }
+static inline int pick_act_threads(int N) { (void)N; return 512; }
 
 struct ActPlan {
     int threads;
@@ -1385,24 +1382,28 @@ struct ActPlan {
     size_t lds;
 };
 
-// LDS budget: 160 KiB per CU.  Prefer two resident workgroups per CU (<= 80 KiB each) with
-// the walls/anthill bitmaps staged too; otherwise one 1024-thread workgroup per CU.
+// LDS budget: 160 KiB per CU.  Preference order is MEASURED (c3, MI355X): keeping the walls/anthill
+// bitmaps in LDS with two workgroups per CU (0.344 ms) beats three workgroups per CU that fetch
+// those bits through L1/L2 (0.382 ms) — the kernel is bound by its memory pipeline, not by
+// occupancy.  So: bitmaps in LDS at 3 then 2 workgroups per CU, only then the global-bitmap plans,
+// then one 1024-thread workgroup, then 512 threads with the whole CU's LDS.
+// ANTSRL_ACT_PLAN=<n> pins candidate n (A/B runs).
 static ActPlan plan_act(const KP &p)
 {
     const size_t cap = 160 * 1024;
-    const int t0 = pick_act_threads(p.N);
-    // {threads, walls/anthill bitmaps in LDS, LDS limit}: prefer two resident workgroups per
-    // CU (<= 80 KiB each), then one 1024-thread workgroup, then fewer waves (smaller staging).
     const struct { int threads; bool st; size_t limit; } cand[] = {
-        {t0, true, cap / 2}, {t0, false, cap / 2}, {1024, true, cap}, {1024, false, cap},
-        {512, false, cap},   {256, false, cap},
+        {512, true, cap / 3},  {512, true, cap / 2},  {512, false, cap / 3}, {512, false, cap / 2},
+        {1024, true, cap},     {1024, false, cap},    {512, false, cap},
     };
+    static const int pin = getenv("ANTSRL_ACT_PLAN") ? atoi(getenv("ANTSRL_ACT_PLAN")) : -1;
     ActPlan pl{};
+    int k = 0;
     for (const auto &c : cand) {
         pl.threads = c.threads;
         pl.static_lds = c.st;
         pl.lds = act_lds_bytes(p.N, p.PP, p.words, p.HT, p.K, c.threads / 64, c.st, nullptr, nullptr, p.R);
-        if (pl.lds <= c.limit) return pl;
+        if (pin >= 0 ? k == pin : pl.lds <= c.limit) return pl;
+        ++k;
     }
     return pl; // caller checks pl.lds <= cap
 }
@@ -1420,21 +1421,33 @@ static int act_layout(const KP &p)
     return p.K == 6 ? LAYOUT_DEFAULT : LAYOUT_DEFAULT_ROCKS;
 }
 
-template <int C, bool ST, int LAYOUT, bool FAST>
-static hipError_t launch_act_k(const KP &p, const ActPlan &pl, const int8_t *rot, const int8_t *ph, int cur,
+template <int C, bool ST, int LAYOUT, bool FAST, int TPB>
+static hipError_t launch_act_t(const KP &p, const ActPlan &pl, const int8_t *rot, const int8_t *ph, int cur,
                                float *obs, float *agent_state, float *reward, uint8_t *done, int flags,
                                const double *jitter, int out_buf, hipStream_t st)
 {
     static size_t attr_lds = 0; // dynamic-LDS opt-in is per kernel function, set once per size
     if (pl.lds > attr_lds) {
-        hipError_t err = hipFuncSetAttribute((const void *)k_act<C, ST, LAYOUT, FAST>,
+        hipError_t err = hipFuncSetAttribute((const void *)k_act<C, ST, LAYOUT, FAST, TPB>,
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds);
         if (err != hipSuccess) return err;
         attr_lds = pl.lds;
     }
-    hipLaunchKernelGGL((k_act<C, ST, LAYOUT, FAST>), dim3(p.E), dim3(pl.threads), pl.lds, st, p, rot, ph, cur, obs,
+    hipLaunchKernelGGL((k_act<C, ST, LAYOUT, FAST, TPB>), dim3(p.E), dim3(TPB), pl.lds, st, p, rot, ph, cur, obs,
                        agent_state, reward, done, flags, jitter, out_buf);
     return hipGetLastError();
+}
+
+template <int C, bool ST, int LAYOUT, bool FAST>
+static hipError_t launch_act_k(const KP &p, const ActPlan &pl, const int8_t *rot, const int8_t *ph, int cur,
+                               float *obs, float *agent_state, float *reward, uint8_t *done, int flags,
+                               const double *jitter, int out_buf, hipStream_t st)
+{
+    if (pl.threads == 1024)
+        return launch_act_t<C, ST, LAYOUT, FAST, 1024>(p, pl, rot, ph, cur, obs, agent_state, reward, done, flags,
+                                                       jitter, out_buf, st);
+    return launch_act_t<C, ST, LAYOUT, FAST, 512>(p, pl, rot, ph, cur, obs, agent_state, reward, done, flags, jitter,
+                                                  out_buf, st);
 }
 
 template <int C>

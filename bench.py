@@ -101,7 +101,7 @@ def cpu_baseline(cfg_kw, make_cfg, synth_init, random_actions, budget_s=15.0):
     one(1)
     one(2)
     per = (time.perf_counter() - t0) / 2
-    steps = int(max(3, min(2000, budget_s / max(per, 1e-6))))
+    steps = int(max(3, min(50000, budget_s / max(per, 1e-6))))
     t0 = time.perf_counter()
     for t in range(steps):
         one(t)
