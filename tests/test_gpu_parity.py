@@ -198,6 +198,54 @@ def test_bench_config_vs_oracle(torch_mod):
     _compare_with_oracle(torch_mod, cfg, synth_init(cfg, seed=77), steps=12, seed=5, jitter_mode="builtin")
 
 
+def test_full_bench_batch_sampled_envs_vs_oracle(torch_mod):
+    """The FULL BASELINE config-3 batch (1024 envs x 512 ants, 256x256, 8 rocks) stepped on the
+    GPU; environments 0, 1, 511, 1022 and 1023 are replayed by the oracle from the same initial
+    arrays, actions and wall-jitter draws (envs are independent, so a sample pins the env-major
+    addressing at scale).  Also: the run is bit-reproducible, and an env's result does not depend
+    on the batch around it."""
+    from antsrl_amd import config as cm
+    from antsrl_amd.batched import BatchedAntsEnv
+    from antsrl_amd.synth import random_actions, synth_init
+    from oracle.oracle import Oracle
+    E, N, steps, pick = 1024, 512, 6, [0, 1, 511, 1022, 1023]
+    cfg = cm.make_cfg(E, N, 256, 256, n_rocks=8, deposit_strength=256.0)
+    cfg_s = cm.make_cfg(len(pick), N, 256, 256, n_rocks=8, deposit_strength=256.0)
+    init = synth_init(cfg, seed=1234)
+    sub = {k: np.ascontiguousarray(v[pick]) for k, v in init.items()}
+    rot, ph = random_actions(cfg, steps, seed=99)
+    rng = np.random.default_rng(17)
+    orc = Oracle(cfg_s, sub, n_threads=5)
+    env, env2, env_s = BatchedAntsEnv(cfg), BatchedAntsEnv(cfg), BatchedAntsEnv(cfg_s)
+    env.reset(init)
+    env2.reset(init)
+    env_s.reset(sub)
+    for t in range(steps):
+        jit = rng.random((E, N))
+        obs, ast, rew, done = env.step_update(rot[t], ph[t], jit)
+        o2 = env2.step_update(rot[t], ph[t], jit)
+        os_ = env_s.step_update(rot[t][pick], ph[t][pick], jit[pick])
+        assert all(torch_mod.equal(a, b) for a, b in zip((obs, ast, rew, done), o2)), "run-to-run difference"
+        assert torch_mod.equal(obs[pick], os_[0]) and torch_mod.equal(rew[pick], os_[2]), "batch dependence"
+        o_obs, o_ast, o_rew, o_done = orc.step(rot[t][pick], ph[t][pick])
+        orc.update(jit[pick])
+        go, gr = _cpu(obs[pick]), _cpu(rew[pick])
+        for j in range(len(pick)):
+            check_obs(cfg_s, go[j], o_obs[j], "full batch step %d env %d" % (t, pick[j]))
+        np.testing.assert_array_equal(gr, o_rew.astype(np.float32))
+    xyt = _cpu(env.read_state(cm.S_ANTS_XYT))
+    np.testing.assert_allclose(xyt[pick], orc.ants_xyt, rtol=0, atol=XY_ATOL)
+    np.testing.assert_array_equal(_cpu(env.read_state(cm.S_FOOD))[pick], orc.food)
+    np.testing.assert_array_equal(_cpu(env.read_state(cm.S_EXPLORED))[pick], orc.explored)
+    assert phero_close(_cpu(env.read_state(cm.S_PHERO))[pick], orc.phero).all()
+    # whole-batch invariants: every env moved, stayed in range, kept its books
+    assert np.isfinite(xyt).all() and xyt[..., 0].min() >= 0 and xyt[..., 0].max() < 256
+    assert (np.abs(xyt[..., :2] - init["ants_xyt"][..., :2]).max(axis=(1, 2)) > 0).all()
+    hold = _cpu(env.read_state(cm.S_HOLDING))
+    assert hold.min() >= 0 and hold.max() <= 5
+    assert (_cpu(env.read_state(cm.S_TIMESTEP)) == steps + 1).all()
+
+
 def test_config2_vs_oracle_injected_jitter(torch_mod):
     from antsrl_amd.config import make_cfg
     from antsrl_amd.synth import synth_init
