@@ -5,14 +5,14 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-from .config import AntsCfg, AntsInit
+from .config import AntsCfg, AntsGen, AntsInit
 
 LIB_PATH = os.environ.get("ANTSRL_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib",
                                                         "libantsrl_hip.so")  # ANTSRL_LIB: A/B builds
 
 #: every symbol include/antsrl.h declares
 EXPORTS = ("antsrl_abi_version", "antsrl_cfg_size", "antsrl_last_error", "antsrl_workspace_bytes", "antsrl_create",
-           "antsrl_destroy", "antsrl_reset", "antsrl_step", "antsrl_observe", "antsrl_update",
+           "antsrl_destroy", "antsrl_reset", "antsrl_generate", "antsrl_step", "antsrl_observe", "antsrl_update",
            "antsrl_step_update", "antsrl_set_timing_events", "antsrl_set_activation", "antsrl_read_state", "antsrl_state_bytes")
 
 _lib = None
@@ -44,6 +44,7 @@ def load() -> C.CDLL:
     lib.antsrl_destroy.argtypes = [vp]
     lib.antsrl_destroy.restype = None
     lib.antsrl_reset.argtypes = [vp, C.POINTER(AntsInit), vp]
+    lib.antsrl_generate.argtypes = [vp, C.POINTER(AntsGen), C.c_uint64, vp]
     lib.antsrl_step.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
     lib.antsrl_observe.argtypes = [vp, vp, vp, vp, vp]
     lib.antsrl_update.argtypes = [vp, vp, vp]

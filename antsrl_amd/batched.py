@@ -99,6 +99,13 @@ class BatchedAntsEnv:
             _lib.check(self.lib.antsrl_reset(self._h, C.byref(ai), self._stream()), "reset")
         self._keep = t  # inputs must outlive the enqueued reset kernels
 
+    def generate(self, gen=None, episode_seed: int = 0) -> None:
+        """Device-side episode generation (antsrl_generate): no host arrays, no upload.  With
+        gen.auto_reset, step_update() regenerates all envs after the step that reported done."""
+        g = gen if gen is not None else cfgmod.make_gen()
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.antsrl_generate(self._h, C.byref(g), int(episode_seed), self._stream()), "generate")
+
     def _actions(self, rotation, phero):
         c = self.cfg
         rot = self._dev(rotation, torch.int8, (c.n_envs, c.n_ants))

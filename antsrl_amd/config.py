@@ -91,6 +91,17 @@ class AntsCfg(C.Structure):
         return (self.n_envs, self.n_ants, p, p, self.n_channels)
 
 
+class AntsGen(C.Structure):
+    """Device-side episode generator parameters (include/antsrl.h: AntsGen)."""
+    _fields_ = [("wall_density", C.c_double), ("n_food_discs", C.c_int32), ("food_rmin", C.c_int32),
+                ("food_rmax", C.c_int32), ("auto_reset", C.c_int32)]
+
+
+def make_gen(wall_density=0.05, n_food_discs=20, food_rmin=5, food_rmax=10, auto_reset=False) -> AntsGen:
+    """Defaults: main.py:74 (CirclesGenerator(20, 5, 10)); walls 5 %."""
+    return AntsGen(wall_density, n_food_discs, food_rmin, food_rmax, 1 if auto_reset else 0)
+
+
 class AntsInit(C.Structure):
     _fields_ = [
         ("ants_xyt", C.c_void_p),
@@ -213,7 +224,7 @@ def mask_array(cfg: AntsCfg) -> Optional[np.ndarray]:
 
 
 __all__ = [n for n in dir() if n.isupper() or n in (
-    "AntsCfg", "AntsInit", "make_cfg", "diffuse_filter", "default_channels", "mask_array")]
+    "AntsCfg", "AntsInit", "AntsGen", "make_gen", "make_cfg", "diffuse_filter", "default_channels", "mask_array")]
 _ = math
 
 

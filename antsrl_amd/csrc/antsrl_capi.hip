@@ -24,6 +24,7 @@ hipError_t antsrl_launch_collect_full(const KP &p, hipStream_t st);
 hipError_t antsrl_launch_reset(const KP &p, const AntsInit *in, hipStream_t st);
 hipError_t antsrl_launch_set_activation(const KP &p, const float *act, hipStream_t st);
 hipError_t antsrl_launch_read_state(const KP &p, int which, int cur, void *dst, hipStream_t st);
+hipError_t antsrl_launch_generate(const KP &p, const AntsGen &g, uint64_t seed, hipStream_t st);
 hipError_t antsrl_launch_phero_wall_clear(const KP &p, hipStream_t st);
 hipError_t antsrl_launch_phero_renorm(const KP &p, hipStream_t st);
 
@@ -35,6 +36,10 @@ struct AntsHandle {
     bool need_full_collect;// next update must run Anthill.update over the whole grid
     bool is_reset;
     size_t ws_bytes;
+    AntsGen gen;           // device generator parameters (antsrl_generate)
+    bool has_gen;
+    uint64_t episode_seed; // seed of the current episode
+    int host_timestep;     // mirrors Environment.timestep (all envs step in lockstep)
     long long sweeps;      // scaled mode: updates since the units were last re-based
     bool need_wall_clear;  // scaled mode: initial grid may hold pheromone on wall cells
     hipEvent_t ev[4];      // measurement hook (antsrl_set_timing_events)
@@ -134,6 +139,7 @@ static size_t carve(const AntsCfg *c, DState *s, unsigned char *base)
     d.rock_r = (double *)take(8 * E * (R ? R : 1)); d.rock_w = (double *)take(8 * E * (R ? R : 1));
     d.timestep = (int32_t *)take(4 * E);
     d.reward_primed = (uint8_t *)take(E);
+    d.gen_discs = (int32_t *)take(4 * E * ANTSRL_MAX_FOOD_DISCS * 3);
     if (s) *s = d;
     return off;
 }
@@ -216,6 +222,7 @@ extern "C" int antsrl_create(const AntsCfg *cfg, void *workspace, size_t workspa
     carve(cfg, &h->p.s, (unsigned char *)workspace);
     h->cur = 0; h->steps_since_update = 0; h->need_full_collect = true; h->is_reset = false;
     h->sweeps = 0; h->need_wall_clear = false;
+    h->has_gen = false; h->episode_seed = 0; h->host_timestep = 1;
     h->ws_bytes = need;
     h->ev_armed = false;
     if (!antsrl_act_fits(h->p)) {
@@ -241,8 +248,33 @@ extern "C" int antsrl_reset(AntsHandle *h, const AntsInit *init, void *stream)
     h->p.deposit_strength = h->cfg.deposit_strength;
     h->cur = 0; h->steps_since_update = 0; h->need_full_collect = true; h->is_reset = true;
     h->sweeps = 0; h->need_wall_clear = h->p.scaled && init->phero != nullptr;
+    h->host_timestep = 1;
     set_decay(h);
     return ANTSRL_OK;
+}
+
+static int do_generate(AntsHandle *h, uint64_t seed, hipStream_t st)
+{
+    hipError_t e = antsrl_launch_generate(h->p, h->gen, seed, st);
+    if (e != hipSuccess) return hip_fail(e, "generate");
+    h->p.deposit_strength = h->cfg.deposit_strength;
+    h->cur = 0; h->steps_since_update = 0; h->need_full_collect = true; h->is_reset = true;
+    h->sweeps = 0; h->need_wall_clear = false; h->host_timestep = 1;
+    h->episode_seed = seed;
+    set_decay(h);
+    return ANTSRL_OK;
+}
+
+extern "C" int antsrl_generate(AntsHandle *h, const AntsGen *gen, uint64_t episode_seed, void *stream)
+{
+    if (!h || !gen) return fail(ANTSRL_E_INVALID, "NULL handle or gen");
+    if (gen->n_food_discs < 0 || gen->n_food_discs > ANTSRL_MAX_FOOD_DISCS)
+        return fail(ANTSRL_E_INVALID, "n_food_discs must be in 0..%d", ANTSRL_MAX_FOOD_DISCS);
+    if (gen->food_rmin < 0 || gen->food_rmax < gen->food_rmin) return fail(ANTSRL_E_INVALID, "bad food radii");
+    if (!(gen->wall_density >= 0.0 && gen->wall_density <= 1.0)) return fail(ANTSRL_E_INVALID, "bad wall_density");
+    h->gen = *gen;
+    h->has_gen = true;
+    return do_generate(h, episode_seed, (hipStream_t)stream);
 }
 
 static int not_reset() { return fail(ANTSRL_E_INVALID, "antsrl_reset has not been called on this handle"); }
@@ -299,6 +331,7 @@ static int do_update(AntsHandle *h, const double *jitter, hipStream_t st, bool s
     }
     if (!h->p.scaled) h->cur ^= 1;
     h->steps_since_update = 0;
+    h->host_timestep++;
     return ANTSRL_OK;
 }
 
@@ -362,8 +395,11 @@ extern "C" int antsrl_step_update(AntsHandle *h, const int8_t *rotation, const i
     int rc = do_step(h, rotation, phero, obs, agent_state, reward, done, st, fuse, wall_jitter);
     if (rc) return rc;
     if (timed) (void)hipEventRecord(h->ev[2], st);
+    const bool was_done = h->host_timestep == h->cfg.max_time; // RL_api.py:200, same for every env
     rc = do_update(h, wall_jitter, st, true, fuse);
     if (timed) (void)hipEventRecord(h->ev[3], st);
+    if (rc == ANTSRL_OK && was_done && h->has_gen && h->gen.auto_reset)
+        rc = do_generate(h, h->episode_seed + 1, st); // next episode, like main.py:69-79 does per episode
     return rc;
 }
 

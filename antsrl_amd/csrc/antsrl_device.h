@@ -33,6 +33,7 @@ struct DState {
     double *rock_cx, *rock_cy, *rock_r, *rock_w; // [E*R]
     int32_t *timestep;                       // [E]
     uint8_t *reward_primed;                  // [E]
+    int32_t *gen_discs;                      // [E][ANTSRL_MAX_FOOD_DISCS][3] food discs of the device generator
 };
 
 // Kernel parameter block, passed by value (lives in the kernarg segment; every field is

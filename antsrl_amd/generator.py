@@ -151,3 +151,70 @@ class EnvironmentGenerator:  # generator/environment_generator.py:19-106
         radius = mask.shape[0] // 2 if mask is not None else 3
         rl_api.setup_perception(radius, perceived, mask, self.perception_shift)  # :102-105
         return env
+
+
+class DeviceEnvironmentGenerator(EnvironmentGenerator):
+    """EnvironmentGenerator whose draws happen ON THE GPU (antsrl_generate): no
+    O(W*H) Python loops (anthill.py:29-33, map_generators.py:42-46), no host arrays, no upload.
+    Walls are independent cells of the given density, food is `n_food_discs` discs of radius
+    food_rmin..food_rmax (CirclesGenerator's family, main.py:74).  Random streams are counter-based,
+    NOT the reference's MT19937: same distribution, different maps.  auto_reset=True regenerates
+    every env (seed+1, seed+2, ...) right after the update of the step that reported done."""
+
+    def __init__(self, w, h, n_ants, n_pheromones, n_rocks, max_steps, seed=0, n_envs=1, wall_density=0.05,
+                 n_food_discs=20, food_rmin=5, food_rmax=10, auto_reset=False):
+        super().__init__(w, h, n_ants, n_pheromones, n_rocks, None, None, max_steps, seed=seed, n_envs=n_envs)
+        self.gen = cm.make_gen(wall_density, n_food_discs, food_rmin, food_rmax, auto_reset)
+
+    def generate(self, rl_api: RLApi) -> Environment:
+        env = Environment(self.w, self.h, self.max_steps)
+        # anthill / rock parameters are only known on the device: the views read them back lazily
+        anthill = _DeviceAnthill(env)
+        perceived = [anthill, Walls(env), Food(env)]
+        if self.n_rocks > 0:
+            perceived.append(_DeviceRocks(env, self.n_rocks))
+        ants = Ants(env, self.n_ants, self.n_envs, 5)
+        perceived.insert(0, ants)
+        for p in range(self.n_pheromones):
+            phero = Pheromone(env, p, color=PHERO_COLORS[p % len(PHERO_COLORS)], max_val=255)
+            ants.register_pheromone(phero)
+            perceived.insert(p + 1, phero)
+        rl_api.register_ants(ants)
+        rl_api._pending = (dict(n_envs=self.n_envs, n_ants=self.n_ants, w=self.w, h=self.h,
+                                n_phero=self.n_pheromones, n_rocks=self.n_rocks, max_time=self.max_steps,
+                                max_hold=5.0, phero_max_val=255.0, deposit_strength=1.0),
+                           ("device", self.gen, int(self.seed or 0)))
+        mask = None if self.perception_mask is None else np.asarray(self.perception_mask)
+        rl_api.setup_perception(mask.shape[0] // 2 if mask is not None else 3, perceived, mask, self.perception_shift)
+        return env
+
+
+class _DeviceAnthill(Anthill):
+    """Anthill view whose x / y / radius come from the device (they change at every auto-reset)."""
+
+    def __init__(self, environment):
+        super().__init__(environment, np.zeros((1, 3), np.int32))
+
+    @property
+    def _xyr_now(self):
+        # area bitmap -> bounding box gives back centre and radius of the rasterised disc
+        a = self._read(cm.S_ANTHILL_AREA).astype(bool)
+        out = np.zeros((a.shape[0], 3), np.int64)
+        for e in range(a.shape[0]):
+            xs, ys = np.nonzero(a[e])
+            out[e] = ((xs.min() + xs.max()) // 2, (ys.min() + ys.max()) // 2, (xs.max() - xs.min()) // 2)
+        return out
+
+    x = property(lambda self: int(self._xyr_now[0, 0]) if self._xyr_now.shape[0] == 1 else self._xyr_now[:, 0])
+    y = property(lambda self: int(self._xyr_now[0, 1]) if self._xyr_now.shape[0] == 1 else self._xyr_now[:, 1])
+    radius = property(lambda self: int(self._xyr_now[0, 2]) if self._xyr_now.shape[0] == 1 else self._xyr_now[:, 2])
+
+    @property
+    def area(self):
+        a = self._read(cm.S_ANTHILL_AREA).astype(bool)
+        return a[0] if a.shape[0] == 1 else a
+
+
+class _DeviceRocks(CircleObstacles):
+    def __init__(self, environment, n_rocks):
+        super().__init__(environment, np.zeros(n_rocks), np.zeros(n_rocks))

@@ -239,6 +239,14 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(dict(N=cfg.n_ants, W=cfg.w, H=cfg.h, extra=extra),
                                                cm.make_cfg, synth_init, random_actions)
+    if rank == 0 and out is not None:
+        # device-side episode reset (antsrl_generate), outside the timed region: how long a whole-batch
+        # "EnvironmentGenerator.generate" takes on the GPU
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        env.generate(cm.make_gen(), episode_seed=1)
+        torch.cuda.synchronize(dev)
+        out["config"]["device_reset_ms"] = round((time.perf_counter() - t1) * 1e3, 3)
     if evs:
         evs.destroy()
     if world > 1:

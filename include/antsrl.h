@@ -141,6 +141,18 @@ typedef struct AntsInit {
     const float *phero;        /* [E][C][W][H] or NULL (= zeros), pheromone.py:28-31 */
 } AntsInit;
 
+/* Parameters of the device-side episode generator (antsrl_generate): the knobs of
+ * EnvironmentGenerator.__init__ / CirclesGenerator (generator/environment_generator.py:20-46,
+ * generator/map_generators.py:28-33, main.py:70-77) that are not already in AntsCfg. */
+#define ANTSRL_MAX_FOOD_DISCS 64
+typedef struct AntsGen {
+    double wall_density;   /* independent wall cells (stand-in for PerlinGenerator: needs `noise`) */
+    int32_t n_food_discs;  /* CirclesGenerator.n_circles, main.py:74 uses 20 (<= ANTSRL_MAX_FOOD_DISCS) */
+    int32_t food_rmin, food_rmax; /* CirclesGenerator min/max radius, main.py:74 uses 5, 10 */
+    int32_t auto_reset;    /* 1: antsrl_step_update regenerates every env right after the update of
+                              the step that reported done (RL_api.py:200), with the next episode seed */
+} AntsGen;
+
 typedef struct AntsHandle AntsHandle;
 
 /* selectors for antsrl_read_state: canonical (reference-shaped) layouts */
@@ -189,6 +201,15 @@ void antsrl_destroy(AntsHandle *h);
  * RLApi.register_ants (RL_api.py:57-66) and Reward.setup (rewards/reward.py:12-19,
  * reward_custom.py:13-15,33-35,65-77).  timestep := 1 (environment.py:27). */
 int antsrl_reset(AntsHandle *h, const AntsInit *init, void *stream);
+
+/* Episode "reset" on the device: draws what EnvironmentGenerator.generate
+ * draws (generator/environment_generator.py:52-106) — anthill in the central half, walls cleared on
+ * the anthill, food discs zeroed on walls, rocks in the generator's band, ants in a disc of 0.8 r
+ * around the anthill — from a counter-based generator keyed on (episode_seed, env, item), and loads it
+ * exactly like antsrl_reset.  The reference draws from Python's `random` / `np.random` (MT19937): equal
+ * seeds do NOT give the reference's maps; the oracle (oracle_generate) restates THIS generator.
+ * With gen->auto_reset the handle keeps `gen` and re-runs it with episode_seed+1, +2, ... */
+int antsrl_generate(AntsHandle *h, const AntsGen *gen, uint64_t episode_seed, void *stream);
 
 /* RLApi.step (environment/RL_api.py:168-204): mandibles/food exchange, pheromone
  * activation, rotate, forward move, observation, reward, done.

@@ -76,6 +76,69 @@ double oracle_jitter_u01(uint64_t seed, uint32_t env, uint32_t timestep, uint32_
     return (double)(k >> 11) * (1.0 / 9007199254740992.0); /* 53-bit mantissa, [0,1) */
 }
 
+/* ---- device-side episode generator restated (antsrl_generate) ----
+ * Same draws as the HIP kernels k_gen_env / k_gen_cells / k_gen_ants, which mirror what
+ * EnvironmentGenerator.generate builds (generator/environment_generator.py:52-106) but from a
+ * counter-based generator instead of Python's MT19937 streams. */
+#define GEN_SALT 0x6A09E667F3BCC909ULL
+enum { GEN_ANTHILL = 0, GEN_WALLS = 1, GEN_FOOD = 2, GEN_ROCKS = 3, GEN_ANT_ANGLE = 4, GEN_ANT_DIST = 5,
+       GEN_ANT_THETA = 6, GEN_ANT_SEED = 7 };
+static double gen_u01(uint64_t seed, uint32_t env, uint32_t tag, uint32_t idx)
+{
+    return oracle_jitter_u01(seed ^ GEN_SALT, env, tag, idx);
+}
+
+void oracle_generate_init(const AntsCfg *c, const AntsGen *g, uint64_t seed, double *ants_xyt, double *seed_out,
+                          uint8_t *walls, float *food, int32_t *xyr, double *rocks)
+{
+    const int W = c->w, H = c->h, N = c->n_ants, R = c->n_rocks, m = W < H ? W : H;
+    const size_t G = (size_t)W * H;
+    for (int e = 0; e < c->n_envs; ++e) {
+        const long ax = (int)(gen_u01(seed, e, GEN_ANTHILL, 0) * W * 0.5 + W * 0.25);   /* :61 */
+        const long ay = (int)(gen_u01(seed, e, GEN_ANTHILL, 1) * H * 0.5 + H * 0.25);   /* :62 */
+        const long ar = (int)(gen_u01(seed, e, GEN_ANTHILL, 2) * m * 0.05 + m * 0.05);  /* :63 */
+        xyr[3 * e] = (int32_t)ax; xyr[3 * e + 1] = (int32_t)ay; xyr[3 * e + 2] = (int32_t)ar;
+        for (int q = 0; q < R; ++q) {                                                   /* :77-85 */
+            double *rk = rocks + ((size_t)e * R + q) * 4;
+            rk[0] = gen_u01(seed, e, GEN_ROCKS, 4 * q + 0) * (W * 0.75) + W * 0.25;
+            rk[1] = gen_u01(seed, e, GEN_ROCKS, 4 * q + 1) * (H * 0.25) + H * 0.25;
+            rk[2] = gen_u01(seed, e, GEN_ROCKS, 4 * q + 2) * 5 + 5;
+            rk[3] = gen_u01(seed, e, GEN_ROCKS, 4 * q + 3) * 50 + 50;
+        }
+        long discs[ANTSRL_MAX_FOOD_DISCS][3];
+        for (int d = 0; d < g->n_food_discs; ++d) {                                     /* map_generators.py:37-40 */
+            long rad = (int)(gen_u01(seed, e, GEN_FOOD, 3 * d + 0) * (g->food_rmax - g->food_rmin) + g->food_rmin);
+            const long cap = (m - 1) / 2;
+            if (rad > cap) rad = cap;
+            discs[d][0] = rad;
+            discs[d][1] = (int)(gen_u01(seed, e, GEN_FOOD, 3 * d + 1) * (W - 2 * rad) + rad);
+            discs[d][2] = (int)(gen_u01(seed, e, GEN_FOOD, 3 * d + 2) * (H - 2 * rad) + rad);
+        }
+        for (long x = 0; x < W; ++x)
+            for (long y = 0; y < H; ++y) {
+                const size_t cell = (size_t)x * H + y;
+                const int area = ar >= 0 && (ax - x) * (ax - x) + (ay - y) * (ay - y) <= ar * ar;
+                const int wall = !area && gen_u01(seed, e, GEN_WALLS, (uint32_t)cell) < g->wall_density; /* :66-67 */
+                int fd = 0;
+                for (int d = 0; d < g->n_food_discs; ++d) {
+                    const long dx = discs[d][1] - x, dy = discs[d][2] - y;
+                    fd |= dx * dx + dy * dy <= discs[d][0] * discs[d][0];
+                }
+                walls[e * G + cell] = (uint8_t)wall;
+                food[e * G + cell] = (fd && !wall) ? 1.0f : 0.0f;                        /* :71-72 */
+            }
+        for (int a = 0; a < N; ++a) {                                                    /* :87-93 */
+            const double ang = gen_u01(seed, e, GEN_ANT_ANGLE, a) * 2 * PI_D;
+            const double dist = gen_u01(seed, e, GEN_ANT_DIST, a) * (double)ar * 0.8;
+            double *o = ants_xyt + ((size_t)e * N + a) * 3;
+            o[0] = cos(ang) * dist + (double)ax;
+            o[1] = sin(ang) * dist + (double)ay;
+            o[2] = gen_u01(seed, e, GEN_ANT_THETA, a) * 2 * PI_D;
+            seed_out[(size_t)e * N + a] = (double)(float)gen_u01(seed, e, GEN_ANT_SEED, a);
+        }
+    }
+}
+
 int oracle_max_threads(void)
 {
 #ifdef _OPENMP

@@ -146,6 +146,21 @@ class Oracle:
         return np.stack([self.rock_cx, self.rock_cy], axis=-1)
 
 
+def generate_init(cfg: AntsCfg, gen, seed: int) -> Dict[str, np.ndarray]:
+    """oracle_generate_init: the device-side episode generator restated on the host."""
+    E, N, W, H, R = cfg.n_envs, cfg.n_ants, cfg.w, cfg.h, cfg.n_rocks
+    out = dict(ants_xyt=np.zeros((E, N, 3)), seed=np.zeros((E, N)), walls=np.zeros((E, W, H), np.uint8),
+               food=np.zeros((E, W, H), np.float32), anthill_xyr=np.zeros((E, 3), np.int32),
+               rocks=np.zeros((E, max(R, 1), 4)))
+    lib().oracle_generate_init(C.byref(cfg), C.byref(gen), C.c_uint64(seed), _p(out["ants_xyt"]), _p(out["seed"]),
+                               _p(out["walls"]), _p(out["food"]), _p(out["anthill_xyr"]), _p(out["rocks"]))
+    if R == 0:
+        out.pop("rocks")
+    else:
+        out["rocks"] = out["rocks"][:, :R]
+    return out
+
+
 def jitter_u01(seed: int, env: int, timestep: int, ant: int) -> float:
     return lib().oracle_jitter_u01(seed, env, timestep, ant)
 

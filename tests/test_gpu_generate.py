@@ -1,0 +1,104 @@
+"""Device-side episode generation and auto-reset against the oracle's
+restatement of the same generator (oracle_generate_init)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _cpu(t):
+    return t.detach().cpu().numpy()
+
+
+def _check_fresh_episode(env, cfg, gen, seed):
+    from antsrl_amd import config as cm
+    from oracle.oracle import Oracle, generate_init
+    init = generate_init(cfg, gen, seed)
+    orc = Oracle(cfg, init)
+    np.testing.assert_array_equal(_cpu(env.read_state(cm.S_WALLS)), init["walls"])
+    np.testing.assert_array_equal(_cpu(env.read_state(cm.S_FOOD)), init["food"])
+    np.testing.assert_array_equal(_cpu(env.read_state(cm.S_ANTHILL_AREA)), orc.anthill_area)
+    np.testing.assert_allclose(_cpu(env.read_state(cm.S_ANTS_XYT)), orc.ants_xyt, rtol=0, atol=1e-11)
+    np.testing.assert_array_equal(_cpu(env.read_state(cm.S_SEED)), init["seed"].astype(np.float32))
+    if cfg.n_rocks:
+        np.testing.assert_array_equal(_cpu(env.read_state(cm.S_ROCK_CENTERS)), init["rocks"][..., :2])
+    assert (_cpu(env.read_state(cm.S_TIMESTEP)) == 1).all()
+    assert _cpu(env.read_state(cm.S_PHERO)).max() == 0 and _cpu(env.read_state(cm.S_EXPLORED)).max() == 0
+    assert _cpu(env.read_state(cm.S_HOLDING)).max() == 0
+    # sanity of what was drawn (environment_generator.py:60-72): anthill in the central half, free of walls
+    xyr = init["anthill_xyr"]
+    assert (xyr[:, 0] >= cfg.w // 4).all() and (xyr[:, 0] < 3 * cfg.w // 4 + 1).all()
+    assert (init["walls"][orc.anthill_area.astype(bool)] == 0).all()
+    assert (init["food"][init["walls"].astype(bool)] == 0).all()
+    return orc
+
+
+def test_generate_matches_oracle_and_steps_in_parity():
+    from antsrl_amd import config as cm
+    from antsrl_amd.batched import BatchedAntsEnv
+    from antsrl_amd.synth import random_actions
+    from test_gpu_parity import check_obs
+    cfg = cm.make_cfg(5, 96, 128, 96, n_rocks=3, deposit_strength=256.0)
+    gen = cm.make_gen(wall_density=0.07, n_food_discs=12, food_rmin=3, food_rmax=8)
+    env = BatchedAntsEnv(cfg)
+    env.generate(gen, episode_seed=42)
+    orc = _check_fresh_episode(env, cfg, gen, 42)
+    rot, ph = random_actions(cfg, 10, seed=1)
+    for t in range(10):
+        obs, ast, rew, done = env.step_update(rot[t], ph[t])
+        o_obs, o_ast, o_rew, o_done = orc.step(rot[t], ph[t])
+        orc.update(None)
+        for e in range(cfg.n_envs):
+            check_obs(cfg, _cpu(obs)[e], o_obs[e], "generated env %d step %d" % (e, t))
+        np.testing.assert_array_equal(_cpu(rew), o_rew.astype(np.float32))
+    np.testing.assert_array_equal(_cpu(env.read_state(cm.S_FOOD)), orc.food)
+    # a different seed gives a different world; the same seed the same one
+    env.generate(gen, episode_seed=43)
+    assert not np.array_equal(_cpu(env.read_state(cm.S_WALLS)), orc.walls)
+    env.generate(gen, episode_seed=42)
+    np.testing.assert_array_equal(_cpu(env.read_state(cm.S_WALLS)), orc.walls)
+
+
+def test_auto_reset_on_done():
+    """max_time = 4: the step with timestep == 4 reports done (RL_api.py:200); right after its update
+    every env is regenerated with episode_seed + 1, and again one episode later."""
+    from antsrl_amd import config as cm
+    from antsrl_amd.batched import BatchedAntsEnv
+    cfg = cm.make_cfg(3, 40, 64, 64, max_time=4, deposit_strength=256.0)
+    gen = cm.make_gen(wall_density=0.05, n_food_discs=6, food_rmin=3, food_rmax=6, auto_reset=True)
+    env = BatchedAntsEnv(cfg)
+    env.generate(gen, episode_seed=7)
+    dones = []
+    rot = np.zeros((3, 40), np.int8)
+    for t in range(9):
+        obs, ast, rew, done = env.step_update(rot, rot)
+        dones.append(int(_cpu(done)[0]))
+        if t == 3:
+            _check_fresh_episode(env, cfg, gen, 8)
+        if t == 7:
+            _check_fresh_episode(env, cfg, gen, 9)
+    # timestep runs 1,2,3,4(done) | 1,2,3,4(done) | 1
+    assert dones == [0, 0, 0, 1, 0, 0, 0, 1, 0]
+
+
+def test_device_generator_behind_the_reference_surface():
+    """DeviceEnvironmentGenerator: same RLApi / Environment wiring as the host generator, state
+    drawn on the GPU, auto-reset at max_steps."""
+    from antsrl_amd.generator import DeviceEnvironmentGenerator
+    from antsrl_amd.rl_api import ExplorationReward, Pheromone, RLApi
+    api = RLApi(ExplorationReward(), 1, 1, 40 / 180 * np.pi, 0.05, 0.5)
+    env = DeviceEnvironmentGenerator(64, 64, 24, 2, 2, max_steps=3, seed=5, n_envs=1, n_food_discs=5,
+                                     food_rmin=2, food_rmax=5, auto_reset=True).generate(api)
+    assert api.ants.n_ants == 24 and len(api.perceived_objects) == 7
+    assert sum(isinstance(o, Pheromone) for o in api.perceived_objects) == 2
+    anthill = [o for o in env.objects if type(o).__name__ == "_DeviceAnthill"][0]
+    assert 16 <= anthill.x <= 48 and 16 <= anthill.y <= 48 and 3 <= anthill.radius <= 6
+    obs, ast, state = api.observation()
+    assert obs.shape == (24, 7, 7, 7)
+    flags = []
+    for t in range(4):
+        o, a, r, d = api.step(np.zeros(24, np.int8), None)
+        env.update()
+        flags.append((d, env.timestep))
+    # separate step()/update() calls do not auto-reset (only the fused antsrl_step_update does)
+    assert [f[0] for f in flags] == [False, False, True, False] and flags[-1][1] == 5
