@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("ANTSRL_LIB") or os.path.join(os.path.dirname(os.path.
 #: every symbol include/antsrl.h declares
 EXPORTS = ("antsrl_abi_version", "antsrl_cfg_size", "antsrl_last_error", "antsrl_workspace_bytes", "antsrl_create",
            "antsrl_destroy", "antsrl_reset", "antsrl_generate", "antsrl_step", "antsrl_observe", "antsrl_update",
-           "antsrl_step_update", "antsrl_set_timing_events", "antsrl_set_activation", "antsrl_read_state", "antsrl_state_bytes")
+           "antsrl_step_update", "antsrl_set_timing_events", "antsrl_set_activation", "antsrl_policy_mlp", "antsrl_read_state", "antsrl_state_bytes")
 
 _lib = None
 
@@ -51,6 +51,7 @@ def load() -> C.CDLL:
     lib.antsrl_step_update.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.antsrl_set_timing_events.argtypes = [vp, C.POINTER(vp)]
     lib.antsrl_set_activation.argtypes = [vp, vp, C.c_double, vp]
+    lib.antsrl_policy_mlp.argtypes = [vp, vp, vp, C.c_int64, C.c_int32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.antsrl_read_state.argtypes = [vp, i32, vp, vp]
     lib.antsrl_state_bytes.argtypes = [vp, i32, C.POINTER(C.c_size_t)]
     for name in EXPORTS:

@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libantsrl_hip.so")
-SOURCES = ["antsrl_kernels.hip", "antsrl_capi.hip"]
+SOURCES = ["antsrl_kernels.hip", "antsrl_capi.hip", "antsrl_policy.hip"]
 HEADERS = [os.path.join(CSRC, "antsrl_device.h"), os.path.join(HERE, "..", "include", "antsrl.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17",
          "-Wall", "-Wno-unused-function"]

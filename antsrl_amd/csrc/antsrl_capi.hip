@@ -422,6 +422,28 @@ extern "C" int antsrl_set_activation(AntsHandle *h, const float *act, double new
     return ANTSRL_OK;
 }
 
+hipError_t antsrl_launch_policy(const float *obs, const float *agent_state, const float *w1, const float *b1,
+                                const float *w2, const float *b2, const float *w3, const float *b3, int8_t *rot,
+                                int8_t *ph, float *logits, int M, int F, hipStream_t st);
+
+extern "C" int antsrl_policy_mlp(AntsHandle *h, const float *obs, const float *agent_state, int64_t n_ants,
+                                 int32_t n_features, const float *w1, const float *b1, const float *w2,
+                                 const float *b2, const float *w3, const float *b3, int8_t *rotation,
+                                 int8_t *pheromone, float *logits, void *stream)
+{
+    (void)h;
+    if (!obs || !agent_state || !w1 || !b1 || !w2 || !b2 || !rotation)
+        return fail(ANTSRL_E_INVALID, "policy_mlp: obs, agent_state, w1, b1, w2, b2, rotation are required");
+    if ((w3 == nullptr) != (b3 == nullptr) || (pheromone && !w3))
+        return fail(ANTSRL_E_INVALID, "policy_mlp: w3/b3 go together and are needed for a pheromone output");
+    if (n_ants < 1 || n_ants > 0x7fffffff || n_features < 1 || n_features + 2 > 1024)
+        return fail(ANTSRL_E_INVALID, "policy_mlp: n_ants >= 1 and 1 <= n_features <= 1022");
+    hipError_t e = antsrl_launch_policy(obs, agent_state, w1, b1, w2, b2, w3, b3, rotation, pheromone, logits,
+                                        (int)n_ants, n_features, (hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail(e, "policy_mlp");
+    return ANTSRL_OK;
+}
+
 static size_t state_bytes(const AntsHandle *h, int which)
 {
     const size_t E = h->p.E, N = h->p.N, G = (size_t)h->p.W * h->p.H, C = h->p.C, R = h->p.R;

@@ -1,0 +1,146 @@
+// antsrl_policy.hip — in-loop policy inference for BASELINE config 5.
+//
+// The reference's DQN agents are tiny linear nets with no activation
+// (agents/explore_agent_pytorch.py:24-45, agents/collect_agent.py:24-51):
+//     out        = layer1(cat[state.view(-1, F), agent_state.view(-1, 2)])        F = P*P*K, 32 hidden
+//     rotations  = layer2(out)   (3)        pheromones = layer3(out)   (3)
+//     rotation   = argmax(rotations) - rotations//2,  pheromone = argmax(pheromones)
+//                  (agents/collect_agent_memory.py:196-199)
+// This IS a dense contraction, so it is the one place on the path that uses MFMA: bf16 operands,
+// fp32 accumulation (v_mfma_f32_32x32x16_bf16).  One wave owns tiles of 32 ants; the first layer is
+// computed TRANSPOSED (A = W1 [32 hidden x k], B = X^T [k x 32 ants]) so that a lane ends up holding
+// 16 of the 32 hidden values of ITS ant, and the heads are a second MFMA that takes that accumulator
+// as its B operand without any lane movement.  W1 is converted to bf16 once per workgroup into LDS;
+// the observation rows stream from HBM exactly once, as 32-byte pieces per lane.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/antsrl.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+#define POL_HIDDEN 32
+#define POL_MAX_KSTEPS 64 // (F + 2) <= 1024 inputs: W1 as bf16 fits 64 KiB of LDS
+
+struct __attribute__((packed, aligned(4))) F4 { float v[4]; }; // 4-byte aligned 16-byte load
+
+__global__ void __launch_bounds__(256)
+k_policy_mlp(const float *__restrict__ obs, const float *__restrict__ agent_state, const float *__restrict__ w1,
+             const float *__restrict__ b1, const float *__restrict__ w2, const float *__restrict__ b2,
+             const float *__restrict__ w3, const float *__restrict__ b3, int8_t *__restrict__ rot_out,
+             int8_t *__restrict__ ph_out, float *__restrict__ logits_out, const int M, const int F,
+             const int ksteps)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    __bf16 *w1s = reinterpret_cast<__bf16 *>(smem); // [32][KP], KP = 16*ksteps + 8 (8 = bank skew)
+    const int KP = 16 * ksteps + 8;
+    const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+    const int IN = F + 2;
+    for (int i = threadIdx.x; i < POL_HIDDEN * 16 * ksteps; i += blockDim.x) {
+        const int row = i / (16 * ksteps), k = i - row * 16 * ksteps;
+        w1s[row * KP + k] = (__bf16)(k < IN ? w1[(size_t)row * IN + k] : 0.0f);
+    }
+    // Heads as a second MFMA: logits^T [32 (6 used) x 32 ants] = W23 [32 x 32 hidden] . H^T, with the
+    // first accumulator reused AS the B operand: its registers 8s..8s+7 (converted to bf16) are the
+    // fragment of k-step s, in the permuted k order  k(j, h) = 16 s + 8 (j >> 2) + 4 h + (j & 3)
+    // (cdna_hip_programming.md, "An accumulator tile as the next MFMA's operand"), so W23's fragment
+    // is loaded in that same order.  Output row o lands in register o of half-wave 0 (o < 4) or
+    // register o - 4 of half-wave 1.
+    bf16x8 a2[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int hid = 16 * s + 8 * (j >> 2) + 4 * h + (j & 3);
+            float w = 0.0f;
+            if (r < 3) w = w2[r * POL_HIDDEN + hid];
+            else if (r < 6 && w3) w = w3[(r - 3) * POL_HIDDEN + hid];
+            a2[s][j] = (__bf16)w;
+        }
+    float bias1[16];
+#pragma unroll
+    for (int g = 0; g < 16; ++g) bias1[g] = b1[(g & 3) + 8 * (g >> 2) + 4 * h];
+    float hb[6];
+#pragma unroll
+    for (int o = 0; o < 6; ++o) hb[o] = o < 3 ? b2[o] : (w3 ? b3[o - 3] : 0.0f);
+    __syncthreads();
+
+    const int ntiles = (M + 31) / 32;
+    const int full = F / 16; // k-steps whose 16 inputs all lie inside the observation row
+    for (int t = wave; t < ntiles; t += nwaves) {
+        const int ant = min(t * 32 + r, M - 1); // clamped: duplicates are not written back
+        const float *row = obs + (size_t)ant * F;
+        const __bf16 *wrow = w1s + r * KP + 8 * h;
+        f32x16 acc;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) acc[g] = 0.0f;
+#pragma unroll 4
+        for (int s = 0; s < full; ++s) {
+            const int k0 = 16 * s + 8 * h;
+            const F4 lo = *reinterpret_cast<const F4 *>(row + k0);
+            const F4 hi = *reinterpret_cast<const F4 *>(row + k0 + 4);
+            bf16x8 bfrag;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { bfrag[j] = (__bf16)lo.v[j]; bfrag[4 + j] = (__bf16)hi.v[j]; }
+            const bf16x8 afrag = *reinterpret_cast<const bf16x8 *>(wrow + 16 * s);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag, acc, 0, 0, 0);
+        }
+        for (int s = full; s < ksteps; ++s) { // tail: end of the row, the two agent_state inputs, zero pad
+            bf16x8 bfrag;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = 16 * s + 8 * h + j;
+                const float x = k < F ? row[k] : (k < IN ? agent_state[(size_t)ant * 2 + (k - F)] : 0.0f);
+                bfrag[j] = (__bf16)x;
+            }
+            const bf16x8 afrag = *reinterpret_cast<const bf16x8 *>(wrow + 16 * s);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag, acc, 0, 0, 0);
+        }
+        // acc[g] = hidden[(g&3) + 8*(g>>2) + 4*h] of ant r (before bias)
+        f32x16 acc2;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) acc2[g] = 0.0f;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            bf16x8 hfrag;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) hfrag[j] = (__bf16)(acc[8 * s + j] + bias1[8 * s + j]);
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[s], hfrag, acc2, 0, 0, 0);
+        }
+        // logits of ant r: rows 0..3 in this lane if h == 0, rows 4,5 in lane r + 32
+        float lg[6];
+        lg[0] = acc2[0]; lg[1] = acc2[1]; lg[2] = acc2[2]; lg[3] = acc2[3];
+        lg[4] = __shfl(acc2[0], r + 32); lg[5] = __shfl(acc2[1], r + 32);
+#pragma unroll
+        for (int o = 0; o < 6; ++o) lg[o] += hb[o];
+        if (h == 0 && t * 32 + r < M) {
+            // torch.max(...).indices: first maximum wins
+            int ar = 0, ap = 0;
+            if (lg[1] > lg[ar]) ar = 1;
+            if (lg[2] > lg[ar]) ar = 2;
+            if (lg[4] > lg[3 + ap]) ap = 1;
+            if (lg[5] > lg[3 + ap]) ap = 2;
+            rot_out[ant] = (int8_t)(ar - 1); // - rotations // 2
+            if (ph_out) ph_out[ant] = (int8_t)ap;
+            if (logits_out)
+#pragma unroll
+                for (int o = 0; o < 6; ++o) logits_out[(size_t)ant * 6 + o] = lg[o];
+        }
+    }
+}
+
+hipError_t antsrl_launch_policy(const float *obs, const float *agent_state, const float *w1, const float *b1,
+                                const float *w2, const float *b2, const float *w3, const float *b3, int8_t *rot,
+                                int8_t *ph, float *logits, int M, int F, hipStream_t st)
+{
+    const int ksteps = (F + 2 + 15) / 16;
+    if (ksteps > POL_MAX_KSTEPS || M < 1 || F < 1) return hipErrorInvalidValue;
+    const int ntiles = (M + 31) / 32;
+    int blocks = (ntiles + 3) / 4;
+    if (blocks > 256 * 4) blocks = 256 * 4; // tiles are looped; 4 workgroups per CU
+    const size_t lds = (size_t)POL_HIDDEN * (16 * ksteps + 8) * 2;
+    hipLaunchKernelGGL(k_policy_mlp, dim3(blocks), dim3(256), lds, st, obs, agent_state, w1, b1, w2, b2, w3, b3, rot,
+                       ph, logits, M, F, ksteps);
+    return hipGetLastError();
+}

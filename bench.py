@@ -33,6 +33,8 @@ CONFIGS = {
                desc="BASELINE configs[2]: 1024 envs x 512 ants, 256x256, circle_obstacles+walls+food"),
     "c4": dict(E=1024, N=1024, W=512, H=512, R=0, radius3=True,
                desc="BASELINE configs[3] per-GPU shard: 1024 envs x 1024 ants, 512x512, diffuse radius 3"),
+    "c5": dict(E=512, N=512, W=256, H=256, R=0, radius3=False, policy="mlp",
+               desc="BASELINE configs[4] per-GPU shard: 512 envs x 512 ants, 256x256, DQN inference in-loop (bf16)"),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 
@@ -121,6 +123,8 @@ def main():
     ap.add_argument("--envs", type=int, default=0, help="override envs per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--policy", default=None, choices=["random", "mlp"],
+                    help="mlp: the reference's linear DQN net evaluated in-loop on the GPU (bf16 MFMA)")
     ap.add_argument("--explicit-sweep", action="store_true",
                     help="force the per-step pheromone sweep kernel (default: scaled units, no sweep)")
     args = ap.parse_args()
@@ -167,8 +171,19 @@ def main():
         from antsrl_amd.dist import RewardGather
         gather = RewardGather(world * E, cfg.n_ants, dev)
 
+    policy_kind = args.policy or W_.get("policy", "random")
+    policy = None
+    if policy_kind == "mlp":
+        from antsrl_amd.policy import LinearPolicy
+        policy = LinearPolicy(cfg.pside * cfg.pside * cfg.n_channels, dev, seed=5 + rank)
+        env.observe()  # main.py:88: first observation feeds the first action
+
     def one_step(t):
-        env.step_update(rot[t % RING], ph[t % RING], None)
+        if policy is not None:  # agent.get_action on the device, then api.step + env.update
+            a_rot, a_ph = policy.act(env.obs, env.agent_state)
+            env.step_update(a_rot, a_ph, None)
+        else:
+            env.step_update(rot[t % RING], ph[t % RING], None)
         if gather is not None:  # the path's only exchange: reward/done all-gather
             gather(env.reward, env.done)
 
@@ -232,7 +247,8 @@ def main():
                        "filter_radius": cfg.filter_radius, "reward": "ExplorationReward",
                        "pheromone_update": "scaled units (no per-step sweep)" if cm.uses_scaled_units(cfg)
                        else "explicit sweep kernel",
-                       "policy": "uniform random, pre-generated on device",
+                       "policy": ("linear DQN net (F+2 -> 32 -> 3+3) in-loop, bf16 MFMA" if policy is not None
+                                  else "uniform random, pre-generated on device"),
                        "parallelism": "env-sharded x%d, reward/done all-gather" % world},
             "roofline": roofline,
         }

@@ -253,6 +253,19 @@ int antsrl_set_timing_events(AntsHandle *h, void *const *events);
 int antsrl_set_activation(AntsHandle *h, const float *act, double new_deposit_strength,
                           void *stream);
 
+/* In-loop policy inference (BASELINE config 5): the reference's linear DQN nets
+ * (agents/explore_agent_pytorch.py:24-45, agents/collect_agent.py:24-51) evaluated on the
+ * observation tensor without leaving the device, bf16 operands / fp32 accumulation (MFMA):
+ *     out = layer1(cat[obs.view(M, F), agent_state.view(M, 2)])   layer1: w1 float [32][F+2], b1 [32]
+ *     rotation  = argmax(layer2(out)) - 1                         layer2: w2 float [3][32],  b2 [3]
+ *     pheromone = argmax(layer3(out))      (skipped if w3 NULL)   layer3: w3 float [3][32],  b3 [3]
+ * Weights are PyTorch nn.Linear layouts, device pointers.  M = number of ants (E*N), F = P*P*K.
+ * rotation/pheromone: int8 [M], directly usable as antsrl_step's actions.  logits (float [M][6],
+ * nullable) receives the six head outputs.  Stateless: `h` only supplies nothing but error context. */
+int antsrl_policy_mlp(AntsHandle *h, const float *obs, const float *agent_state, int64_t n_ants, int32_t n_features,
+                      const float *w1, const float *b1, const float *w2, const float *b2, const float *w3,
+                      const float *b3, int8_t *rotation, int8_t *pheromone, float *logits, void *stream);
+
 /* Copies one piece of state into a caller device buffer in the canonical
  * reference-shaped layout (ANTSRL_S_*).  Replaces attribute reads such as
  * api.ants.ants, pheromone.phero, food.qte, anthill.food. */

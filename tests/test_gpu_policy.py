@@ -1,0 +1,52 @@
+"""In-loop policy inference (antsrl_policy_mlp, bf16 MFMA) against a plain PyTorch fp32 reference of
+the same linear net on the same bf16-rounded operands."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("E,N,R", [(3, 50, 0), (4, 64, 2), (1, 1, 0)])
+def test_policy_matches_torch_reference(E, N, R):
+    import torch
+    from antsrl_amd import config as cm
+    from antsrl_amd.batched import BatchedAntsEnv
+    from antsrl_amd.policy import LinearPolicy
+    from antsrl_amd.synth import synth_init
+    cfg = cm.make_cfg(E, N, 64, 64, n_rocks=R, deposit_strength=256.0)
+    env = BatchedAntsEnv(cfg)
+    env.reset(synth_init(cfg, seed=3, n_food_discs=6, food_rmin=3, food_rmax=6))
+    pol = LinearPolicy(49 * cfg.n_channels, env.device, seed=1)
+    rng = np.random.default_rng(0)
+    for t in range(4):
+        obs, ast, rew, done = env.step_update(rng.integers(-1, 2, (E, N), dtype=np.int8),
+                                              rng.integers(0, 3, (E, N), dtype=np.int8))
+        logits = torch.empty((E * N, 6), dtype=torch.float32, device=env.device)
+        rot, ph = pol.act(obs, ast, logits)
+        ref = pol.reference_logits(obs, ast)
+        # fp32 accumulation order differs (MFMA k-chains vs GEMM): tight absolute tolerance on O(1) logits
+        assert torch.allclose(logits, ref, rtol=0, atol=2e-3), float((logits - ref).abs().max())
+        # actions: equal to the reference argmax wherever its top-2 margin exceeds the tolerance
+        for head, act, off in ((ref[:, :3], rot.reshape(-1) + 1, 0), (ref[:, 3:], ph.reshape(-1), 0)):
+            top2 = head.topk(2, dim=1).values
+            clear = (top2[:, 0] - top2[:, 1]) > 4e-3
+            assert torch.equal(act[clear].long(), head.argmax(dim=1)[clear])
+        assert rot.shape == (E, N) and rot.dtype == torch.int8 and int(rot.min()) >= -1 and int(rot.max()) <= 1
+        assert int(ph.min()) >= 0 and int(ph.max()) <= 2
+    # the actions drive the next step directly (config 5's loop)
+    obs, ast, rew, done = env.step_update(rot, ph)
+
+
+def test_policy_rotation_only_head():
+    import torch
+    from antsrl_amd.policy import LinearPolicy
+    dev = torch.device("cuda")
+    pol = LinearPolicy(49 * 6, dev, with_pheromone_head=False, seed=2)
+    obs = torch.rand((70, 7, 7, 6), device=dev)
+    ast = torch.rand((70, 2), device=dev)
+    rot, ph = pol.act(obs, ast)
+    assert ph is None and rot.shape == (70,)
+    ref = pol.reference_logits(obs, ast)
+    top2 = ref.topk(2, dim=1).values
+    clear = (top2[:, 0] - top2[:, 1]) > 4e-3
+    assert torch.equal((rot + 1)[clear].long(), ref.argmax(dim=1)[clear])
