@@ -7,10 +7,16 @@ data-path collective.  The ONLY exchange is the all-gather of reward[E_local, N]
 done[E_local] (u8) each step, so that every rank / the host sees the full batch.
 
 Backend "nccl" is RCCL on ROCm (over xGMI inside a node); "gloo" is used by the CPU tests.
+
+The gather is ONE collective per step: reward and done travel in a single fused fp32 buffer
+[E_local, N+1] (done in the last column — xGMI all-gathers of this size are latency-bound, so one
+2 MiB message beats two), and it can run asynchronously under the next step's kernels
+(`start` / `finish`): the payload is copied out of the live reward tensor first, because the next
+step overwrites it.
 """
 from __future__ import annotations
 
-from typing import Tuple
+from typing import Optional, Tuple
 
 import torch
 import torch.distributed as dist
@@ -24,8 +30,7 @@ def shard_range(n_envs_total: int, rank: int, world: int) -> Tuple[int, int]:
 
 
 class RewardGather:
-    """Pre-allocated all-gather of (reward, done).  Equal shards use all_gather_into_tensor (one
-    fused buffer per tensor, no per-rank list); ragged shards fall back to padded gathers."""
+    """Pre-allocated all-gather of (reward, done) across the ranks that share an env batch."""
 
     def __init__(self, n_envs_total: int, n_ants: int, device, group=None):
         self.group = group
@@ -35,24 +40,38 @@ class RewardGather:
         self.ranges = [shard_range(n_envs_total, r, self.world) for r in range(self.world)]
         self.max_local = max(hi - lo for lo, hi in self.ranges)
         self.equal = all(hi - lo == self.max_local for lo, hi in self.ranges)
-        self.reward_all = torch.empty((self.world * self.max_local, n_ants), dtype=torch.float32, device=device)
-        self.done_all = torch.empty((self.world * self.max_local,), dtype=torch.uint8, device=device)
+        # fused payload: [max_local, N+1] per rank, column N carries `done`
+        self._send = torch.zeros((self.max_local, n_ants + 1), dtype=torch.float32, device=device)
+        self._recv = torch.empty((self.world * self.max_local, n_ants + 1), dtype=torch.float32, device=device)
+        self._work: Optional[dist.Work] = None
         if not self.equal:
-            self._pad_r = torch.zeros((self.max_local, n_ants), dtype=torch.float32, device=device)
-            self._pad_d = torch.zeros((self.max_local,), dtype=torch.uint8, device=device)
+            self._keep = torch.cat([torch.arange(r * self.max_local, r * self.max_local + (h - l))
+                                    for r, (l, h) in enumerate(self.ranges)]).to(device)
 
-    def __call__(self, reward_local: torch.Tensor, done_local: torch.Tensor):
-        """-> (reward [E_total, N], done [E_total]) on every rank (views of internal buffers)."""
+    def start(self, reward_local: torch.Tensor, done_local: torch.Tensor) -> None:
+        """Snapshot this rank's (reward, done) and launch the all-gather without blocking the
+        current stream; the caller may enqueue the next step right away."""
         lo, hi = self.ranges[self.rank]
         assert reward_local.shape == (hi - lo, self.N) and done_local.shape == (hi - lo,)
-        if self.equal:
-            dist.all_gather_into_tensor(self.reward_all, reward_local.contiguous(), group=self.group)
-            dist.all_gather_into_tensor(self.done_all, done_local.contiguous(), group=self.group)
-            return self.reward_all, self.done_all
-        self._pad_r[: hi - lo] = reward_local
-        self._pad_d[: hi - lo] = done_local
-        dist.all_gather_into_tensor(self.reward_all, self._pad_r, group=self.group)
-        dist.all_gather_into_tensor(self.done_all, self._pad_d, group=self.group)
-        keep = torch.cat([torch.arange(r * self.max_local, r * self.max_local + (h - l))
-                          for r, (l, h) in enumerate(self.ranges)]).to(self.reward_all.device)
-        return self.reward_all[keep], self.done_all[keep]
+        self.finish()  # the send buffer is reused: the previous gather must have consumed it
+        self._send[: hi - lo, : self.N].copy_(reward_local)
+        self._send[: hi - lo, self.N].copy_(done_local)
+        self._work = dist.all_gather_into_tensor(self._recv, self._send, group=self.group, async_op=True)
+
+    def finish(self):
+        """Wait for the gather launched by start(); -> (reward [E_total, N], done [E_total] uint8) on
+        every rank, or None if nothing is pending."""
+        if self._work is None:
+            return None
+        self._work.wait()
+        self._work = None
+        return self.result()
+
+    def result(self):
+        full = self._recv if self.equal else self._recv[self._keep]
+        return full[:, : self.N], full[:, self.N].to(torch.uint8)
+
+    def __call__(self, reward_local: torch.Tensor, done_local: torch.Tensor):
+        """Blocking form: -> (reward [E_total, N], done [E_total]) on every rank."""
+        self.start(reward_local, done_local)
+        return self.finish()

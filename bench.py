@@ -184,8 +184,10 @@ def main():
             env.step_update(a_rot, a_ph, None)
         else:
             env.step_update(rot[t % RING], ph[t % RING], None)
-        if gather is not None:  # the path's only exchange: reward/done all-gather
-            gather(env.reward, env.done)
+        if gather is not None:
+            # the path's only exchange: the reward/done all-gather, one fused
+            # collective per step, left running under the next step's kernels
+            gather.start(env.reward, env.done)
 
     for t in range(args.warmup):
         one_step(t)
@@ -199,6 +201,8 @@ def main():
     evs = HipEvents(4 * len(timed_steps)) if timing else None
 
     def barrier():
+        if gather is not None:
+            gather.finish()  # the last step's gather belongs to the timed region
         torch.cuda.synchronize(dev)
         if world > 1:
             dist.barrier()

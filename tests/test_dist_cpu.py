@@ -36,7 +36,13 @@ def _worker(rank, world, port, E, N, q):
         for step in range(3):
             rew = torch.full((hi - lo, N), float(step)) + torch.arange(lo, hi, dtype=torch.float32)[:, None]
             done = torch.tensor([(e + step) % 2 for e in range(lo, hi)], dtype=torch.uint8)
-            r, d = g(rew, done)
+            if step % 2 == 0:
+                r, d = g(rew, done)  # blocking form
+            else:  # overlapped form: the caller's buffers may be overwritten right after start()
+                g.start(rew, done)
+                rew.fill_(-1.0)
+                done.fill_(9)
+                r, d = g.finish()
             out.append((r.clone().numpy(), d.clone().numpy()))
         q.put((rank, init["ants_xyt"], out))
     finally:
