@@ -71,3 +71,4 @@ struct KP {
 #define ACT_ABL_NO_GATHER 512  // no pheromone/food gathers
 #define ACT_ABL_NO_STORE 1024  // no observation stores
 #define ACT_ABL_NO_EXPLORE 2048 // no explored-map test/mark
+#define ACT_ABL_TRACE 32768      // (results stay valid) record the per-workgroup phase timeline, see act_trace

@@ -115,6 +115,17 @@ __device__ __forceinline__ void wave_lds_sync()
     __builtin_amdgcn_wave_barrier();
 }
 
+// Streaming stores for the step's OUTPUT tensors (observation, agent_state, reward): nobody on the
+// device re-reads them within the step, and at 0.7 GB per launch a cached write stream evicts the
+// pheromone/food lines the perception gathers reuse and the ant state k_update reads next
+// (measured on c3, same box: k_act 0.340 -> 0.287 ms, k_update 0.051 -> 0.043 ms).
+typedef float stream_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store_stream(float *dst, float v) { __builtin_nontemporal_store(v, dst); }
+__device__ __forceinline__ void store_stream(float4 *dst, const float4 &v)
+{
+    __builtin_nontemporal_store(stream_f4{v.x, v.y, v.z, v.w}, reinterpret_cast<stream_f4 *>(dst));
+}
+
 __host__ __device__ __forceinline__ size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 // ===================================================================================
@@ -151,42 +162,50 @@ struct ActLds {
 #define ACT_UNROLL 2                 // ants in flight per wave (all their gathers are issued before the first is consumed)
 #define ACT_ITEMS (64 * ACT_UNROLL)  // work items per wave per iteration
 
-__host__ __device__ __forceinline__ size_t act_lds_bytes(int N, int PP, int words, int HT, int K, int nwaves,
-                                                bool static_lds, ActLds *o, unsigned char *base, int R = 0)
+// Byte offsets of the k_act LDS carve.  Plain integers on purpose: the kernel forms its LDS pointers
+// locally from `smem + offset`, so they keep the LDS address space no matter what the optimiser does
+// (a struct of pointers filled through an out-parameter ends up in scratch once the kernel grows, and
+// every LDS access then degrades to flat_* with vmcnt(0) waits).
+struct ActOff {
+    uint32_t frame, off, cnt, rm, pres, old, walls, area, mask, rock, uni, stride;
+    size_t total;
+};
+
+__host__ __device__ __forceinline__ ActOff act_offsets(int N, int PP, int words, int HT, int K, int nwaves,
+                                                       bool static_lds, int R)
 {
+    ActOff o;
     size_t off = 0;
     auto take = [&](size_t bytes) {
         size_t at = off;
         off = (off + bytes + 15) / 16 * 16;
-        return at;
+        return (uint32_t)at;
     };
-    size_t a_fr = take(sizeof(AntFrame) * (size_t)N);
-    size_t a_off = take(sizeof(CellOff) * (size_t)PP);
-    size_t a_cnt = take(4 * (size_t)N), a_rm = take(4 * (size_t)N);
-    size_t a_pres = take(4 * (size_t)words), a_old = take(4 * (size_t)words);
-    size_t a_w = 0, a_a = 0;
+    o.frame = take(sizeof(AntFrame) * (size_t)N);
+    o.off = take(sizeof(CellOff) * (size_t)PP);
+    o.cnt = take(4 * (size_t)N);
+    o.rm = take(4 * (size_t)N);
+    o.pres = take(4 * (size_t)words);
+    o.old = take(4 * (size_t)words);
+    o.walls = o.area = 0;
     if (static_lds) {
-        a_w = take(4 * (size_t)words);
-        a_a = take(4 * (size_t)words);
+        o.walls = take(4 * (size_t)words);
+        o.area = take(4 * (size_t)words);
     }
-    size_t a_mask = take((size_t)PP);
-    size_t a_rock = take(24 * (size_t)(R > 0 ? R : 1));
+    o.mask = take((size_t)PP);
+    o.rock = take(24 * (size_t)(R > 0 ? R : 1));
     const size_t stride = ((size_t)PP * K + 3 + 3) / 4 * 4; // row + up to 3 floats of misalignment
-    size_t hash_b = update_scratch_bytes(HT, R, nwaves), stage_b = 4 * (size_t)nwaves * stride;
-    size_t a_u = take(hash_b > stage_b ? hash_b : stage_b);
-    if (o) {
-        o->frame = (AntFrame *)(base + a_fr);
-        o->off = (CellOff *)(base + a_off);
-        o->cnt = (uint32_t *)(base + a_cnt); o->rockmask = (uint32_t *)(base + a_rm);
-        o->b_pres = (uint32_t *)(base + a_pres); o->b_old = (uint32_t *)(base + a_old);
-        o->b_walls = (uint32_t *)(base + a_w); o->b_area = (uint32_t *)(base + a_a);
-        o->t_mask = base + a_mask;
-        o->rock = (double *)(base + a_rock);
-        o->stage_stride = (uint32_t)stride;
-        o->hkeys = (uint32_t *)(base + a_u); o->hvals = o->hkeys + HT;
-        o->stage = (float *)(base + a_u);
-    }
-    return off;
+    const size_t hash_b = update_scratch_bytes(HT, R, nwaves), stage_b = 4 * (size_t)nwaves * stride;
+    o.uni = take(hash_b > stage_b ? hash_b : stage_b);
+    o.stride = (uint32_t)stride;
+    o.total = off;
+    return o;
+}
+
+__host__ __device__ __forceinline__ size_t act_lds_bytes(int N, int PP, int words, int HT, int K, int nwaves,
+                                                         bool static_lds, void *, unsigned char *, int R = 0)
+{
+    return act_offsets(N, PP, words, HT, K, nwaves, static_lds, R).total;
 }
 
 // Perception-channel layouts known at compile time (straight-line output code); anything else
@@ -194,6 +213,32 @@ __host__ __device__ __forceinline__ size_t act_lds_bytes(int N, int PP, int word
 #define LAYOUT_GENERIC 0
 #define LAYOUT_DEFAULT 1       // [Ants, Phero0, Phero1, Anthill, Walls, Food]   (generator order)
 #define LAYOUT_DEFAULT_ROCKS 2 // ... + [CircleObstacles]
+
+// Profiling only (ANTSRL_ABLATE bit ACT_ABL_TRACE): per-workgroup phase timeline of k_act.  Slot k of
+// workgroup e = s_memrealtime (100 MHz) at: 0 entry, 1 after phase 2, 2 after phase 3, 3 exit;
+// slot 4 = HW_ID, slot 5 = XCC_ID, slot 6 after phase 0, slot 7 after phase 1.  Read back with antsrl_debug_read_act_trace.
+#define ACT_TRACE_SLOTS 8
+#define ACT_TRACE_MAX_WG 8192
+__device__ unsigned long long g_act_trace[ACT_TRACE_SLOTS * ACT_TRACE_MAX_WG];
+
+__device__ __forceinline__ void act_trace(int flags, int e, int tid, int slot)
+{
+    if ((flags & ACT_ABL_TRACE) && tid == 0 && e < ACT_TRACE_MAX_WG) {
+        g_act_trace[e * ACT_TRACE_SLOTS + slot] = wall_clock64();
+        if (slot == 0) {
+            g_act_trace[e * ACT_TRACE_SLOTS + 4] = __builtin_amdgcn_s_getreg(4 | (31 << 11));  // HW_REG_HW_ID
+            g_act_trace[e * ACT_TRACE_SLOTS + 5] = __builtin_amdgcn_s_getreg(20 | (31 << 11)); // HW_REG_XCC_ID
+        }
+    }
+}
+
+extern "C" int antsrl_debug_read_act_trace(unsigned long long *dst, int n_wg)
+{
+    if (!dst || n_wg < 0 || n_wg > ACT_TRACE_MAX_WG) return ANTSRL_E_INVALID;
+    if (hipDeviceSynchronize() != hipSuccess) return ANTSRL_E_DEVICE;
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_act_trace), sizeof(unsigned long long) * ACT_TRACE_SLOTS * (size_t)n_wg)
+                   == hipSuccess ? ANTSRL_OK : ANTSRL_E_DEVICE;
+}
 
 // FAST selects the software-pipelined perception loop (see phase 3); the two loops live in
 // separate instantiations on purpose: with both in one kernel the optimiser stops scalarising the
@@ -208,11 +253,26 @@ k_act(const KP p, const int8_t *__restrict__ rotation, const int8_t *__restrict_
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const int e = blockIdx.x, tid = threadIdx.x, T = blockDim.x;
-    const int lane = tid & 63, wave = tid >> 6, nwaves = T >> 6;
+    // the wave index is wave-uniform: say so, and every per-ant address below is computed on the SALU
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwaves = T >> 6;
     const int N = p.N, W = p.W, H = p.H, K = p.K, P = p.P, PP = p.PP, R = p.R;
     const size_t G = (size_t)W * H;
-    ActLds L;
-    act_lds_bytes(N, PP, p.words, p.HT, K, nwaves, STATIC_LDS, &L, smem, R);
+    const ActOff lo = act_offsets(N, PP, p.words, p.HT, K, nwaves, STATIC_LDS, R);
+    ActLds L; // filled field by field right here: never has its address taken, stays in registers
+    L.frame = (AntFrame *)(smem + lo.frame);
+    L.off = (CellOff *)(smem + lo.off);
+    L.cnt = (uint32_t *)(smem + lo.cnt);
+    L.rockmask = (uint32_t *)(smem + lo.rm);
+    L.b_pres = (uint32_t *)(smem + lo.pres);
+    L.b_old = (uint32_t *)(smem + lo.old);
+    L.b_walls = (uint32_t *)(smem + lo.walls);
+    L.b_area = (uint32_t *)(smem + lo.area);
+    L.t_mask = smem + lo.mask;
+    L.rock = (double *)(smem + lo.rock);
+    L.hkeys = (uint32_t *)(smem + lo.uni);
+    L.hvals = L.hkeys + p.HT;
+    L.stage = (float *)(smem + lo.uni);
+    L.stage_stride = lo.stride;
 
     const size_t eN = (size_t)e * N;
     const uint32_t *g_walls = p.s.walls_bits + (size_t)e * p.words;
@@ -226,6 +286,7 @@ k_act(const KP p, const int8_t *__restrict__ rotation, const int8_t *__restrict_
     const bool explore = p.explore_on != 0;
     const uint8_t primed0 = p.s.reward_primed[e];
 
+    act_trace(flags, e, tid, 0);
     // ---- phase 0: stage bitmaps and tables in LDS
     for (int w = tid; w < p.words; w += T) {
         L.b_pres[w] = 0u;
@@ -252,6 +313,7 @@ k_act(const KP p, const int8_t *__restrict__ rotation, const int8_t *__restrict_
             L.hvals[h] = 0u;
         }
     __syncthreads();
+    act_trace(flags, e, tid, 6);
 
     if (do_step) {
         // ---- phase 1a: mandible target (RL_api.py:178-185) + Ants.update_mandibles reads
@@ -293,6 +355,7 @@ k_act(const KP p, const int8_t *__restrict__ rotation, const int8_t *__restrict_
         }
         __syncthreads();
     }
+    act_trace(flags, e, tid, 7);
 
     // ---- phase 2: activation, rotate, move (RL_api.py:187-196) and the perception frame
     const double margin = (double)p.r * p.delta * 1.4142135623730951 + 1.5;
@@ -350,6 +413,7 @@ k_act(const KP p, const int8_t *__restrict__ rotation, const int8_t *__restrict_
         L.rockmask[i] = rm;
     }
     __syncthreads();
+    act_trace(flags, e, tid, 1);
 
     // ---- phase 3: perception gather, RL_api.py:109-148.  One WAVE per ant, one LANE per perceived
     //      cell (49 of 64 lanes at the reference's 7x7): the cell's offsets, mask bit and output slot
@@ -367,6 +431,7 @@ k_act(const KP p, const int8_t *__restrict__ rotation, const int8_t *__restrict_
     float *stage = L.stage + (size_t)wave * L.stage_stride;
     const bool wrap_fast = W > 4 * (p.r + 4) && H > 4 * (p.r + 4) && p.fwd_delta < W / 4 && p.fwd_delta < H / 4 &&
                            p.fwd_delta > -W / 4 && p.fwd_delta > -H / 4 && p.delta < 2.0; // one conditional add wraps
+    const bool wrap_pow2 = (W & (W - 1)) == 0 && (H & (H - 1)) == 0;
     // Fast path (single pass: PP <= 64, row <= 508 floats — the reference's 7x7 with up to 10
     // channels): software-pipelined by one group of ACT_UNROLL ants.  Everything that touches
     // global memory is STRAIGHT-LINE and unconditional (out-of-range ants/lanes are clamped onto
@@ -390,9 +455,11 @@ k_act(const KP p, const int8_t *__restrict__ rotation, const int8_t *__restrict_
             const double rx = fr.ct * of.px - fr.st * of.py; /* RL_api.py:110-111 */                     \
             const double ry = fr.st * of.px + fr.ct * of.py;                                             \
             int ix = (int)rint(rx + fr.cx), iy = (int)rint(ry + fr.cy); /* :114-117 half to even */      \
-            if (wrap_fast) { /* :118-119 */                                                              \
-                ix += ix < 0 ? W : 0; ix -= ix >= W ? W : 0;                                             \
-                iy += iy < 0 ? H : 0; iy -= iy >= H ? H : 0;                                             \
+            if (wrap_pow2) { /* :118-119; two's complement AND is the floor-mod for a power of two */    \
+                ix &= W - 1; iy &= H - 1;                                                                \
+            } else if (wrap_fast) { /* |ix| < 2W: unsigned min picks the in-range candidate */           \
+                ix = (int)min(min((uint32_t)ix, (uint32_t)(ix + W)), (uint32_t)(ix - W));                \
+                iy = (int)min(min((uint32_t)iy, (uint32_t)(iy + H)), (uint32_t)(iy - H));                \
             } else {                                                                                     \
                 ix = wrap_index(ix, W); iy = wrap_index(iy, H);                                          \
             }                                                                                            \
@@ -402,27 +469,33 @@ k_act(const KP p, const int8_t *__restrict__ rotation, const int8_t *__restrict_
         /* unconditional gathers (masked cells too: in bounds, discarded) */                             \
         _Pragma("unroll") for (int u = 0; u < ACT_UNROLL; ++u)                                           \
         {                                                                                                \
+            const uint32_t gc_ = CELL[u];                                                                \
             if (C == 2) {                                                                                \
-                const float2 t = *reinterpret_cast<const float2 *>(ph + (size_t)CELL[u] * 2);            \
+                const float2 t = *reinterpret_cast<const float2 *>(ph + (size_t)gc_ * 2);                \
                 PVV[u][0] = t.x; PVV[u][C - 1] = t.y;                                                    \
             } else {                                                                                     \
-                _Pragma("unroll") for (int c = 0; c < C; ++c) PVV[u][c] = ph[(size_t)CELL[u] * C + c];  \
+                _Pragma("unroll") for (int c = 0; c < C; ++c) PVV[u][c] = ph[(size_t)gc_ * C + c];       \
             }                                                                                            \
-            FDV[u] = food[CELL[u]];                                                                      \
+            FDV[u] = food[gc_];                                                                          \
         }                                                                                                \
     }
         uint32_t c_cell[ACT_UNROLL], n_cell[ACT_UNROLL];
         int c_ix[ACT_UNROLL], c_iy[ACT_UNROLL], n_ix[ACT_UNROLL], n_iy[ACT_UNROLL];
         float c_pv[ACT_UNROLL][C], n_pv[ACT_UNROLL][C], c_fd[ACT_UNROLL], n_fd[ACT_UNROLL];
-        const int gstep = nwaves * ACT_UNROLL;
-        ACT_FETCH(wave * ACT_UNROLL, c_cell, c_ix, c_iy, c_pv, c_fd)
-        for (int i0 = wave * ACT_UNROLL; i0 < N; i0 += gstep) {
+        // Each wave owns a CONTIGUOUS run of ants, so its observation rows form one sequential write
+        // stream: the partial cache line at the end of a row is completed by the same wave's next row
+        // while it is still in L2 (profiles/obs_write_probe.hip: 4.2 -> 4.9 TB/s for this pattern
+        // against a run interleaved over the waves).
+        const int per = ((N + nwaves - 1) / nwaves + ACT_UNROLL - 1) / ACT_UNROLL * ACT_UNROLL;
+        const int i_begin = min(wave * per, N), i_end = min(i_begin + per, N);
+        ACT_FETCH(i_begin, c_cell, c_ix, c_iy, c_pv, c_fd)
+        for (int i0 = i_begin; i0 < i_end; i0 += ACT_UNROLL) {
             // prefetch the next group (clamped: harmless re-read at the end)
-            ACT_FETCH(min(i0 + gstep, N - 1), n_cell, n_ix, n_iy, n_pv, n_fd)
+            ACT_FETCH(min(i0 + ACT_UNROLL, N - 1), n_cell, n_ix, n_iy, n_pv, n_fd)
 #pragma unroll
             for (int u = 0; u < ACT_UNROLL; ++u) {
-                const int i = min(i0 + u, N - 1);
-                const bool real = (i0 + u < N) && lane < PP; // clamped duplicates must not count twice
+                const int i = min(i0 + u, i_end - 1);
+                const bool real = (i0 + u < i_end) && lane < PP; // clamped duplicates must not count twice
                 const uint32_t cl = c_cell[u];
                 const uint32_t wd = cl >> 5, bit = 1u << (cl & 31);
                 if (real && explore && !(L.b_old[wd] & bit)) { // reward_custom.py:19,22 (mask ignored)
@@ -496,9 +569,9 @@ k_act(const KP p, const int8_t *__restrict__ rotation, const int8_t *__restrict_
                 const uint32_t fe = (uint32_t)lane < hd ? mis + lane
                                     : ((uint32_t)lane - hd < tl ? 4 * j_hi + ((uint32_t)lane - hd) : mis);
                 const float ve = stage[fe];
-                reinterpret_cast<float4 *>(dst_al)[ja] = va;
-                reinterpret_cast<float4 *>(dst_al)[jb] = vb;
-                dst_al[fe] = ve;
+                store_stream(reinterpret_cast<float4 *>(dst_al) + ja, va);
+                store_stream(reinterpret_cast<float4 *>(dst_al) + jb, vb);
+                store_stream(dst_al + fe, ve);
                 wave_lds_sync();
             }
 #pragma unroll
@@ -637,12 +710,12 @@ k_act(const KP p, const int8_t *__restrict__ rotation, const int8_t *__restrict_
                             const float4 v = reinterpret_cast<const float4 *>(stage)[j];
                             const uint32_t lo = 4 * j;
                             if (lo >= mis && lo + 3 < mis + row) {
-                                reinterpret_cast<float4 *>(dst_al)[j] = v;
+                                store_stream(reinterpret_cast<float4 *>(dst_al) + j, v);
                             } else {
-                                if (lo + 0 >= mis && lo + 0 < mis + row) dst_al[lo + 0] = v.x;
-                                if (lo + 1 >= mis && lo + 1 < mis + row) dst_al[lo + 1] = v.y;
-                                if (lo + 2 >= mis && lo + 2 < mis + row) dst_al[lo + 2] = v.z;
-                                if (lo + 3 >= mis && lo + 3 < mis + row) dst_al[lo + 3] = v.w;
+                                if (lo + 0 >= mis && lo + 0 < mis + row) store_stream(dst_al + lo + 0, v.x);
+                                if (lo + 1 >= mis && lo + 1 < mis + row) store_stream(dst_al + lo + 1, v.y);
+                                if (lo + 2 >= mis && lo + 2 < mis + row) store_stream(dst_al + lo + 2, v.z);
+                                if (lo + 3 >= mis && lo + 3 < mis + row) store_stream(dst_al + lo + 3, v.w);
                             }
                         }
                     }
@@ -652,13 +725,14 @@ k_act(const KP p, const int8_t *__restrict__ rotation, const int8_t *__restrict_
         }
     }
     __syncthreads();
+    act_trace(flags, e, tid, 2);
 
     // ---- phase 4: agent_state (RL_api.py:160-162), reward.observation hooks, give_reward
     for (int i = tid; i < N; i += T) {
         const float hold = p.s.holding[eN + i];
         if (agent_state) {
-            agent_state[(eN + i) * 2 + 0] = hold;
-            agent_state[(eN + i) * 2 + 1] = p.s.seed[eN + i];
+            store_stream(agent_state + (eN + i) * 2 + 0, hold);
+            store_stream(agent_state + (eN + i) * 2 + 1, p.s.seed[eN + i]);
         }
         double rw = 0.0;
         if (p.reward_kind != ANTSRL_REWARD_NONE) {
@@ -688,13 +762,14 @@ k_act(const KP p, const int8_t *__restrict__ rotation, const int8_t *__restrict_
                 rw += r_food * p.fct_food + r_anthill * p.fct_anthill + heading * p.fct_heading;
             }
         }
-        if (reward) reward[eN + i] = (float)rw;
+        if (reward) store_stream(reward + eN + i, (float)rw);
         if (do_step && rw - p.reward_threshold > 0) p.s.reward_state[eN + i] = 255; // ants.py:119-121
     }
     if (tid == 0) {
         if (p.reward_kind != ANTSRL_REWARD_NONE) p.s.reward_primed[e] = 1;
         if (do_step && done) done[e] = (uint8_t)(p.max_time == p.s.timestep[e]); // RL_api.py:200
     }
+    act_trace(flags, e, tid, 3);
     if (flags & ACT_FUSED_UPDATE) {
         // Environment.update of the same step (main.py:131) in the same launch: the staging
         // region is dead after phase 3 and doubles as the update's scratch.

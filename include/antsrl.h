@@ -247,6 +247,12 @@ int antsrl_step_update(AntsHandle *h, const int8_t *rotation, const int8_t *pher
  * clears itself. */
 int antsrl_set_timing_events(AntsHandle *h, void *const *events);
 
+/* Profiling read-out (no reference counterpart).  With ANTSRL_ABLATE=32768 in the environment the
+ * act kernel stamps a per-workgroup phase timeline; this copies the first n_wg records (8 x u64 each:
+ * 100 MHz timestamps at entry / perception start / perception end / exit, then HW_ID and XCC_ID) to
+ * host memory `dst`.  Synchronises the device. */
+int antsrl_debug_read_act_trace(unsigned long long *dst, int n_wg);
+
 /* Ants.activate_all_pheromones (environment/ants.py:86-87).  act: float [E][N][C].
  * new_deposit_strength > 0 also changes AntsCfg.deposit_strength (the dtype switch
  * of SURVEY.md §8(a) A4); pass 0 to keep it. */
