@@ -1064,7 +1064,7 @@ k_sweep0(const KP p, const float *__restrict__ in, float *__restrict__ out)
             if (clip) f = fminf(f, mx);
             r[j] = f;
         }
-        dst[v] = make_float4(r[0], r[1], r[2], r[3]);
+        store_stream(dst + v, make_float4(r[0], r[1], r[2], r[3]));
     }
 }
 
@@ -1289,7 +1289,9 @@ k_sweep_march(const KP p, const float *__restrict__ in, float *__restrict__ out,
                 }
                 const size_t o = ((size_t)x * H + y) * C;
                 if (C == 2) {
-                    *reinterpret_cast<float2 *>(dst + o) = make_float2(r[0], r[C - 1]);
+                    // streaming store (see store_stream): the next reader is a later kernel
+                    typedef float vf2_t __attribute__((ext_vector_type(2)));
+                    __builtin_nontemporal_store(vf2_t{r[0], r[C - 1]}, reinterpret_cast<vf2_t *>(dst + o));
                 } else {
 #pragma unroll
                     for (int c = 0; c < C; ++c) dst[o + c] = r[c];
