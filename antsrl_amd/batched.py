@@ -26,6 +26,7 @@ _STATE_DTYPES = {
     cfgmod.S_FOOD: torch.float32, cfgmod.S_EXPLORED: torch.uint8, cfgmod.S_ANTHILL_FOOD: torch.float64,
     cfgmod.S_ROCK_CENTERS: torch.float64, cfgmod.S_TIMESTEP: torch.int32, cfgmod.S_REWARD_STATE: torch.uint8,
     cfgmod.S_WALLS: torch.uint8, cfgmod.S_ANTHILL_AREA: torch.uint8, cfgmod.S_SEED: torch.float32,
+    cfgmod.S_ANTHILL_XYR: torch.int32, cfgmod.S_ROCK_RW: torch.float64,
 }
 
 
@@ -173,6 +174,7 @@ class BatchedAntsEnv:
             cfgmod.S_FOOD: (E, W, H), cfgmod.S_EXPLORED: (E, W, H), cfgmod.S_ANTHILL_FOOD: (E,),
             cfgmod.S_ROCK_CENTERS: (E, R, 2), cfgmod.S_TIMESTEP: (E,), cfgmod.S_REWARD_STATE: (E, N),
             cfgmod.S_WALLS: (E, W, H), cfgmod.S_ANTHILL_AREA: (E, W, H), cfgmod.S_SEED: (E, N),
+            cfgmod.S_ANTHILL_XYR: (E, 3), cfgmod.S_ROCK_RW: (E, R, 2),
         }
         out = torch.empty(shapes[which], dtype=_STATE_DTYPES[which], device=self.device)
         if out.numel():

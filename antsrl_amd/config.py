@@ -32,7 +32,7 @@ PHERO_AUTO, PHERO_EXPLICIT_SWEEP = 0, 1
 
 (S_ANTS_XYT, S_PREV_XY, S_HOLDING, S_MANDIBLES, S_ACTIVATION, S_PHERO, S_FOOD, S_EXPLORED,
  S_ANTHILL_FOOD, S_ROCK_CENTERS, S_TIMESTEP, S_REWARD_STATE, S_WALLS, S_ANTHILL_AREA,
- S_SEED) = range(15)
+ S_SEED, S_ANTHILL_XYR, S_ROCK_RW) = range(17)
 
 
 class AntsCfg(C.Structure):

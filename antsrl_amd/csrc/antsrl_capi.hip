@@ -459,6 +459,8 @@ static size_t state_bytes(const AntsHandle *h, int which)
     case ANTSRL_S_ANTHILL_FOOD: return 8 * E;
     case ANTSRL_S_ROCK_CENTERS: return 8 * E * R * 2;
     case ANTSRL_S_TIMESTEP: return 4 * E;
+    case ANTSRL_S_ANTHILL_XYR: return 4 * E * 3;
+    case ANTSRL_S_ROCK_RW: return 8 * E * R * 2;
     default: return 0;
     }
 }

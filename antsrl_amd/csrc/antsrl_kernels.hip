@@ -1539,6 +1539,13 @@ __global__ void k_read_state(const KP p, const int which, const int cur, void *_
     } break;
     case ANTSRL_S_ANTHILL_FOOD: for (size_t i = t0; i < (size_t)p.E; i += stride) ((double *)dstv)[i] = p.s.anthill_food[i]; break;
     case ANTSRL_S_TIMESTEP: for (size_t i = t0; i < (size_t)p.E; i += stride) ((int32_t *)dstv)[i] = p.s.timestep[i]; break;
+    case ANTSRL_S_ANTHILL_XYR: for (size_t i = t0; i < (size_t)p.E * 3; i += stride) ((int32_t *)dstv)[i] = p.s.anthill_xyr[i]; break;
+    case ANTSRL_S_ROCK_RW:
+        for (size_t i = t0; i < (size_t)p.E * p.R; i += stride) {
+            ((double *)dstv)[2 * i] = p.s.rock_r[i];
+            ((double *)dstv)[2 * i + 1] = p.s.rock_w[i];
+        }
+        break;
     case ANTSRL_S_ROCK_CENTERS:
         for (size_t i = t0; i < (size_t)p.E * p.R; i += stride) {
             ((double *)dstv)[2 * i] = p.s.rock_cx[i];

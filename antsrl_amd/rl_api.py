@@ -39,7 +39,7 @@ class EnvObject:  # environment/environment.py:5-18
             self.environment.add_object(self)
 
     def visualize_copy(self, newenv):
-        return EnvObject(newenv)
+        return None  # nothing to draw (environment.py:11-12 copies an empty EnvObject)
 
     def update(self):
         pass
@@ -75,18 +75,16 @@ class Environment:  # environment/environment.py:21-47
         self._backend.update(wall_jitter)
 
     def save_state(self):
-        """Environment.save_state (environment.py:36-40): a host snapshot for the visualiser."""
-        snap = Environment(self.w, self.h, self.max_time)
+        """Environment.save_state (environment.py:36-40): a host snapshot for the visualiser, in the
+        reference's pickled layout (antsrl_amd.snapshot; write a list of them with snapshot.dump).
+        Each object appears once (the reference's copies register themselves AND are added again by
+        save_state, environment.py:8,39 — the viewer draws such an object twice to the same effect)."""
+        from . import snapshot as S
+        ts = self.timestep
+        snap = S.Environment(self.w, self.h, self.max_time, int(np.asarray(ts).reshape(-1)[0]))
         for obj in self.objects:
-            snap.add_object(obj.visualize_copy(snap))
+            obj.visualize_copy(snap)  # the snapshot classes register themselves with `snap`
         return snap
-
-
-class _Snapshot(EnvObject):
-    def __init__(self, env, **kw):
-        super().__init__(None)
-        self.environment = env
-        self.__dict__.update(kw)
 
 
 class _View(EnvObject):
@@ -116,8 +114,9 @@ class Pheromone(_View):  # environment/pheromone.py:20-45
         return p[0] if p.shape[0] == 1 else p
 
     def visualize_copy(self, newenv):
-        return _Snapshot(newenv, color=self.color, max_val=self.max_val,
-                         phero=np.asarray(self.phero).astype(np.uint8))  # pheromone.py:17
+        from .snapshot import PheromoneVisualization
+        return PheromoneVisualization(newenv, color=self.color, max_val=self.max_val,
+                                      phero=np.asarray(self.phero).astype(np.uint8))  # pheromone.py:17
 
 
 class Food(_View):  # environment/food.py:12-18
@@ -127,7 +126,8 @@ class Food(_View):  # environment/food.py:12-18
         return q[0] if q.shape[0] == 1 else q
 
     def visualize_copy(self, newenv):
-        return _Snapshot(newenv, qte=np.asarray(self.qte).astype(np.uint8))  # food.py:10
+        from .snapshot import FoodVisualization
+        return FoodVisualization(newenv, qte=np.asarray(self.qte).astype(np.uint8))  # food.py:10
 
 
 class Walls(_View):  # environment/walls.py:9-30
@@ -146,8 +146,9 @@ class Walls(_View):  # environment/walls.py:9-30
     def update_step(self):
         return -1
 
-    def visualize_copy(self, newenv):
-        return self
+    def visualize_copy(self, newenv):  # walls.py:16-17 keeps the object itself: same attributes
+        from .snapshot import Walls as WallsSnapshot
+        return WallsSnapshot(newenv, w=self.w, h=self.h, map=np.array(self.map))
 
 
 class Anthill(_View):  # environment/anthill.py:16-46
@@ -185,7 +186,8 @@ class Anthill(_View):  # environment/anthill.py:16-46
         return 1000
 
     def visualize_copy(self, newenv):
-        return _Snapshot(newenv, x=self.x, y=self.y, radius=self.radius, food=self.food)
+        from .snapshot import AnthillVisualization
+        return AnthillVisualization(newenv, x=self.x, y=self.y, radius=self.radius, food=self.food)
 
 
 class CircleObstacles(_View):  # environment/circle_obstacles.py:15-61
@@ -201,8 +203,9 @@ class CircleObstacles(_View):  # environment/circle_obstacles.py:15-61
         return c[0] if c.shape[0] == 1 else c
 
     def visualize_copy(self, newenv):
-        return _Snapshot(newenv, centers=np.array(self.centers), radiuses=np.array(self.radiuses),
-                         weights=np.array(self.weights))
+        from .snapshot import CircleObstaclesVisualization
+        return CircleObstaclesVisualization(newenv, centers=np.array(self.centers), radiuses=np.array(self.radiuses),
+                                            weights=np.array(self.weights))
 
 
 class Ants(_View):  # environment/ants.py:17-144
@@ -276,8 +279,9 @@ class Ants(_View):  # environment/ants.py:17-144
         return 999
 
     def visualize_copy(self, newenv):
-        return _Snapshot(newenv, ants=self.ants, mandibles=self.mandibles, holding=self.holding,
-                         reward_state=self.reward_state)
+        from .snapshot import AntsVisualization
+        return AntsVisualization(newenv, ants=self.ants, mandibles=self.mandibles, holding=self.holding,
+                                 reward_state=self.reward_state)
 
 
 # ----------------------------------------------------------------------------- rewards
@@ -452,4 +456,5 @@ class RLApi(EnvObject):  # environment/RL_api.py:22-204
         return self._out(obs), self._out(ast), r, d
 
     def visualize_copy(self, newenv):
-        return _Snapshot(newenv, heatmap=self.reward.visualization())
+        from .snapshot import RLVisualization
+        return RLVisualization(newenv, heatmap=self.reward.visualization())

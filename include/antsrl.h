@@ -172,6 +172,8 @@ enum {
     ANTSRL_S_WALLS = 12,       /* uint8   [E][W][H]                     */
     ANTSRL_S_ANTHILL_AREA = 13,/* uint8   [E][W][H]   Anthill.area      */
     ANTSRL_S_SEED = 14,        /* float   [E][N]                        */
+    ANTSRL_S_ANTHILL_XYR = 15, /* int32   [E][3]      Anthill.x, .y, .radius (anthill.py:21-23) */
+    ANTSRL_S_ROCK_RW = 16,     /* double  [E][R][2]   CircleObstacles.radiuses, .weights (circle_obstacles.py:19-20) */
     ANTSRL_S_COUNT_
 };
 

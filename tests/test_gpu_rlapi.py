@@ -89,3 +89,55 @@ def test_rlapi_batched_fold_and_device_tensors():
     assert obs.is_cuda and obs.shape == (64, 7, 7, 7) and rew.shape == (64,) and done.shape == (4,)
     env.update()
     assert (env.timestep == 2).all()
+
+
+def test_saved_states_pickle_in_the_reference_layout():
+    """Environment.save_state (environment.py:36-40) per step, as main.py:138-144 does, then the
+    pickled file read back: the last snapshot equals the golden run's final state."""
+    from antsrl_amd import snapshot as S
+    api, env, F, meta = build("s02_walls")
+    states = []
+    for t, op in enumerate(F["ops"]):
+        if op == OP_STEP:
+            api.step(F["rot"][t], F["ph"][t])
+        elif op == OP_UPDATE:
+            env.update(F["jitter"][t][None])
+            states.append(env.save_state())
+    back = S.loads(S.dumps(states))
+    assert len(back) == len(states) and back[-1].timestep == F["timestep"][-1]
+    last = {type(o).__name__: o for o in back[-1].objects}
+    np.testing.assert_allclose(last["AntsVisualization"].ants, F["ants"][-1], rtol=0, atol=1e-9)
+    np.testing.assert_array_equal(last["AntsVisualization"].holding, F["holding"][-1])
+    np.testing.assert_array_equal(last["FoodVisualization"].qte, F["food"][-1].astype(np.uint8))
+    assert last["AnthillVisualization"].food == F["anthill_food"][-1]
+    assert last["Walls"].map.dtype == bool and last["Walls"].map.shape == (meta["w"], meta["h"])
+    np.testing.assert_array_equal(last["RLVisualization"].heatmap, F["explored"][-1].astype(bool))
+    ph = [o for o in back[-1].objects if type(o).__name__ == "PheromoneVisualization"]
+    assert len(ph) == 2 and ph[0].phero.dtype == np.uint8
+    assert np.abs(ph[0].phero.astype(int) - F["phero"][-1][0].astype(np.uint8).astype(int)).max() <= 1
+
+
+def test_snapshot_of_chosen_envs_from_the_batched_backend():
+    import torch
+    from antsrl_amd import config as cm, snapshot as S
+    from antsrl_amd.batched import BatchedAntsEnv
+    from antsrl_amd.synth import random_actions, synth_init
+    cfg = cm.make_cfg(6, 40, 48, 40, n_rocks=3, deposit_strength=256.0)
+    benv = BatchedAntsEnv(cfg, torch.device("cuda", 0))
+    init = synth_init(cfg, seed=3)
+    benv.reset(init)
+    rot, ph = random_actions(cfg, 5, seed=1)
+    for t in range(5):
+        benv.step_update(rot[t], ph[t], None)
+    snaps = S.snapshot_batched(benv, [1, 4])
+    xyt = benv.read_state(cm.S_ANTS_XYT).cpu().numpy()
+    for s, e in zip(snaps, (1, 4)):
+        o = {type(x).__name__: x for x in s.objects}
+        assert s.timestep == 6 and (s.w, s.h) == (48, 40)
+        np.testing.assert_array_equal(o["AntsVisualization"].ants, xyt[e])
+        assert (o["AnthillVisualization"].x, o["AnthillVisualization"].y, o["AnthillVisualization"].radius) == tuple(
+            int(v) for v in init["anthill_xyr"][e])
+        np.testing.assert_array_equal(o["CircleObstaclesVisualization"].radiuses, init["rocks"][e][:, 2])
+        np.testing.assert_array_equal(o["CircleObstaclesVisualization"].weights, init["rocks"][e][:, 3])
+        np.testing.assert_array_equal(o["Walls"].map, init["walls"][e].astype(bool))
+    assert len(S.loads(S.dumps(snaps))) == 2
