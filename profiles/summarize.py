@@ -24,7 +24,8 @@ out = os.path.join(ROOT, "profiles", rnd)
 os.makedirs(out, exist_ok=True)
 st = glob.glob(os.path.join(ROOT, "gpurun_out", stats_dir, "*", "*_kernel_stats.csv"))
 if st:
-    rows = [r for r in csv.reader(open(st[0]))]
+    st.sort(key=os.path.getmtime)
+    rows = [r for r in csv.reader(open(st[-1]))]
     keep = [rows[0]] + [r for r in rows[1:] if "k_" in r[0][:12] or r[0].startswith("void k_")]
     csv.writer(open(os.path.join(out, "kernel_stats.csv"), "w")).writerows(keep)
 summary = {}
@@ -33,7 +34,8 @@ for tag in pmc:
     if not fs:
         continue
     agg = collections.defaultdict(list)
-    for r in csv.DictReader(open(fs[0])):
+    fs.sort(key=os.path.getmtime)  # gpurun_out/ accumulates earlier runs: take the newest
+    for r in csv.DictReader(open(fs[-1])):
         k = r["Kernel_Name"].split("(")[0].replace("void ", "")
         if k.startswith(("k_act", "k_sweep", "k_update")):
             agg[(k.split("<")[0] + ("" if not tag.startswith("x_") else "@explicit"), r["Counter_Name"])].append(
