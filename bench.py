@@ -121,6 +121,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
     ap.add_argument("--envs", type=int, default=0, help="override envs per GPU")
+    ap.add_argument("--rocks", type=int, default=-1, help="override the number of circle obstacles (profiling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--policy", default=None, choices=["random", "mlp"],
@@ -150,7 +151,9 @@ def main():
     from antsrl_amd.batched import BatchedAntsEnv
     from antsrl_amd.synth import random_actions, synth_init
 
-    W_ = CONFIGS[args.config]
+    W_ = dict(CONFIGS[args.config])
+    if args.rocks >= 0:
+        W_["R"] = args.rocks
     E = args.envs or W_["E"]
     extra = dict(n_rocks=W_["R"], deposit_strength=256.0, max_time=1 << 30,
                  phero_mode=cm.PHERO_EXPLICIT_SWEEP if args.explicit_sweep else cm.PHERO_AUTO)
