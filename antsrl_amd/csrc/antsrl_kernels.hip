@@ -287,13 +287,51 @@ k_act(const KP p, const int8_t *__restrict__ rotation, const int8_t *__restrict_
     const uint8_t primed0 = p.s.reward_primed[e];
 
     act_trace(flags, e, tid, 0);
-    // ---- phase 0: stage bitmaps and tables in LDS
-    for (int w = tid; w < p.words; w += T) {
-        L.b_pres[w] = 0u;
-        L.b_old[w] = g_expl[w];
-        if (STATIC_LDS) {
-            L.b_walls[w] = g_walls[w];
-            L.b_area[w] = g_area[w];
+    // With one ant per thread (N <= T: the reference's sizes) every independent global load of the ant is
+    // issued HERE, ahead of the bitmap staging and the first barrier, and the phases below use the
+    // registers: otherwise each phase starts with a dependent round trip to HBM behind a barrier
+    // (14 us of a 100 us workgroup at c3, with the memory system idle).
+    const bool one = N <= T; // wave-uniform
+    const size_t a1 = eN + (tid < N ? tid : 0);
+    double h_x = 0.0, h_y = 0.0, h_th = 0.0;
+    float h_hold = 0.0f, h_q = 0.0f;
+    int h_m = 0, h_rot = 0, h_pa = 0;
+    uint32_t h_cprev = 0u;
+    if (one) {
+        h_x = p.s.x[a1]; h_y = p.s.y[a1]; h_th = p.s.theta[a1];
+        h_hold = p.s.holding[a1];
+        if (do_step) {
+            const double ppx = p.s.prev_x[a1], ppy = p.s.prev_y[a1];
+            h_m = p.s.mandibles[a1];
+            if (rotation) h_rot = rotation[a1];
+            if (phero_act) h_pa = phero_act[a1];
+            h_cprev = (uint32_t)((int)ppx * H + (int)ppy);
+            h_q = food[h_cprev]; // food is first written in phase 1b
+        }
+    }
+    // ---- phase 0: stage bitmaps and tables in LDS (16 bytes per lane, all loads of a pass in flight)
+    {
+        const int w4n = (p.words & 3) ? 0 : p.words >> 2; // env bases stay 16-byte aligned only then
+        const uint4 *o4 = reinterpret_cast<const uint4 *>(g_expl), *wl4 = reinterpret_cast<const uint4 *>(g_walls),
+                    *ar4 = reinterpret_cast<const uint4 *>(g_area);
+        for (int w = tid; w < w4n; w += T) { // (the bitmap arrays are 256-byte aligned in the workspace)
+            const uint4 vo = o4[w];
+            uint4 vw = make_uint4(0, 0, 0, 0), va = vw;
+            if (STATIC_LDS) { vw = wl4[w]; va = ar4[w]; }
+            reinterpret_cast<uint4 *>(L.b_pres)[w] = make_uint4(0, 0, 0, 0);
+            reinterpret_cast<uint4 *>(L.b_old)[w] = vo;
+            if (STATIC_LDS) {
+                reinterpret_cast<uint4 *>(L.b_walls)[w] = vw;
+                reinterpret_cast<uint4 *>(L.b_area)[w] = va;
+            }
+        }
+        for (int w = 4 * w4n + tid; w < p.words; w += T) {
+            L.b_pres[w] = 0u;
+            L.b_old[w] = g_expl[w];
+            if (STATIC_LDS) {
+                L.b_walls[w] = g_walls[w];
+                L.b_area[w] = g_area[w];
+            }
         }
     }
     for (int q = tid; q < PP; q += T) {
@@ -320,21 +358,30 @@ k_act(const KP p, const int8_t *__restrict__ rotation, const int8_t *__restrict_
         //      (ants.py:102-114).  All food reads happen before any food write.
         float *tmp_q = (float *)L.frame, *tmp_d = tmp_q + N; // frame memory is free until phase 2
         for (int i = tid; i < N; i += T) {
-            const double x = p.s.x[eN + i], y = p.s.y[eN + i];
-            const uint32_t cprev = (uint32_t)((int)p.s.prev_x[eN + i] * H + (int)p.s.prev_y[eN + i]);
+            double x, y;
+            uint32_t cprev;
+            float q, hold;
+            int old_m;
+            if (one) {
+                x = h_x; y = h_y; cprev = h_cprev; q = h_q; old_m = h_m; hold = h_hold;
+            } else {
+                x = p.s.x[eN + i]; y = p.s.y[eN + i];
+                cprev = (uint32_t)((int)p.s.prev_x[eN + i] * H + (int)p.s.prev_y[eN + i]);
+                q = food[cprev];
+                old_m = p.s.mandibles[eN + i];
+                hold = p.s.holding[eN + i];
+            }
             const uint32_t ccur = (uint32_t)((int)x * H + (int)y);
-            const float q = food[cprev];
-            const int old_m = p.s.mandibles[eN + i];
             int m = old_m;
             for (int k = 0; k < K; ++k) { // perceived_objects order matters
                 if (p.ch_kind[k] == ANTSRL_CH_FOOD) m = (q > 0.0f) | m;                      // :182
                 else if (p.ch_kind[k] == ANTSRL_CH_ANTHILL) m = (1 - (int)test_bit(area, ccur)) & m; // :184
             }
             const int closing = m & (1 - old_m), opening = (1 - m) & old_m; // ants.py:103-104
-            const float hold = p.s.holding[eN + i];
             const float taken = fminf((float)p.max_hold, fmaxf(0.0f, q)) * (float)closing; // :111
             const float dropped = hold * (float)opening;                                    // :114
-            p.s.holding[eN + i] = hold + (taken - dropped);                                 // :117
+            h_hold = hold + (taken - dropped);                                              // :117
+            p.s.holding[eN + i] = h_hold;
             p.s.mandibles[eN + i] = (uint8_t)m;                                             // :107
             L.cnt[i] = cprev;
             tmp_q[i] = q;
@@ -360,10 +407,15 @@ k_act(const KP p, const int8_t *__restrict__ rotation, const int8_t *__restrict_
     // ---- phase 2: activation, rotate, move (RL_api.py:187-196) and the perception frame
     const double margin = (double)p.r * p.delta * 1.4142135623730951 + 1.5;
     for (int i = tid; i < N; i += T) {
-        double x = p.s.x[eN + i], y = p.s.y[eN + i], th = p.s.theta[eN + i];
+        double x, y, th;
+        if (one) {
+            x = h_x; y = h_y; th = h_th;
+        } else {
+            x = p.s.x[eN + i]; y = p.s.y[eN + i]; th = p.s.theta[eN + i];
+        }
         if (do_step) {
             if (phero_act) { // Ants.activate_pheromone, ants.py:89-96
-                const int a = phero_act[eN + i];
+                const int a = one ? h_pa : (int)phero_act[eN + i];
                 float a0 = 0.0f, a1 = 0.0f;
                 if (a == 1) a0 = (float)p.deposit_strength;
                 else if (a != 0) a1 = (float)p.deposit_strength;
@@ -371,13 +423,13 @@ k_act(const KP p, const int8_t *__restrict__ rotation, const int8_t *__restrict_
                 if (C > 1) p.s.activation[(eN + i) * C + 1] = a1;
             }
             if (rotation) // Ants.rotate_ants + warp_theta, ants.py:62-67
-                th = np_mod_d(th + (double)rotation[eN + i] * p.max_rot_speed, 2 * PI_D);
+                th = np_mod_d(th + (double)(one ? h_rot : (int)rotation[eN + i]) * p.max_rot_speed, 2 * PI_D);
         }
         double sn, cs;
         sincos(th, &sn, &cs);
         if (do_step) {
             // RL_api.py:194-196, Ants.forward_ants ants.py:77-80
-            double fwd = 1.0 * p.max_speed * (1 - (double)p.s.holding[eN + i] * p.carry);
+            double fwd = 1.0 * p.max_speed * (1 - (double)(one ? h_hold : p.s.holding[eN + i]) * p.carry);
             if (fwd < 0) fwd *= p.backward;
             x = warp_coord(x + cs * fwd, (double)W);
             y = warp_coord(y + sn * fwd, (double)H);
