@@ -23,6 +23,16 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 #define POL_MAX_KSTEPS 64 // (F + 2) <= 1024 inputs: W1 as bf16 fits 64 KiB of LDS
 
 struct __attribute__((packed, aligned(4))) F4 { float v[4]; }; // 4-byte aligned 16-byte load
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+#define POL_KC 64                 // inputs per staged chunk (4 MFMA k-steps)
+#define POL_SROW (POL_KC + 8)     // bf16 per staged row: 144-byte stride = 16-byte aligned rows, 4-bank skew per row
+
+__device__ __forceinline__ void pol_wave_sync()
+{
+    // LDS hand-off inside one wave: its LDS instructions execute in order, only the compiler must not reorder
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
 
 __global__ void __launch_bounds__(256)
 k_policy_mlp(const float *__restrict__ obs, const float *__restrict__ agent_state, const float *__restrict__ w1,
@@ -37,10 +47,9 @@ k_policy_mlp(const float *__restrict__ obs, const float *__restrict__ agent_stat
     const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
     const int IN = F + 2;
-    for (int i = threadIdx.x; i < POL_HIDDEN * 16 * ksteps; i += blockDim.x) {
-        const int row = i / (16 * ksteps), k = i - row * 16 * ksteps;
-        w1s[row * KP + k] = (__bf16)(k < IN ? w1[(size_t)row * IN + k] : 0.0f);
-    }
+    for (int row = threadIdx.x >> 6; row < POL_HIDDEN; row += blockDim.x >> 6) // a wave per row: no divisions
+        for (int k = lane; k < 16 * ksteps; k += 64)
+            w1s[row * KP + k] = (__bf16)(k < IN ? w1[(size_t)row * IN + k] : 0.0f);
     // Heads as a second MFMA: logits^T [32 (6 used) x 32 ants] = W23 [32 x 32 hidden] . H^T, with the
     // first accumulator reused AS the B operand: its registers 8s..8s+7 (converted to bf16) are the
     // fragment of k-step s, in the permuted k order  k(j, h) = 16 s + 8 (j >> 2) + 4 h + (j & 3)
@@ -66,37 +75,70 @@ k_policy_mlp(const float *__restrict__ obs, const float *__restrict__ agent_stat
     for (int o = 0; o < 6; ++o) hb[o] = o < 3 ? b2[o] : (w3 ? b3[o - 3] : 0.0f);
     __syncthreads();
 
+    // The 32 rows of a tile are CONTIGUOUS in `obs` (32 * F floats).  They are streamed in chunks of
+    // POL_KC inputs: a lane group of 16 reads 256 contiguous bytes of one ant's row, 4 ants per load
+    // instruction (coalesced; a lane-per-ant read touches 32+ cache lines per instruction), converted to
+    // bf16 and transposed through a wave-private LDS tile into the MFMA's B-fragment order (lane (r, h)
+    // of k-step s holds inputs 16 s + 8 h .. + 7 of ant r).  Chunk c + 1 is in flight while chunk c is
+    // converted and multiplied.
     const int ntiles = (M + 31) / 32;
-    const int full = F / 16; // k-steps whose 16 inputs all lie inside the observation row
+    const int wib = threadIdx.x >> 6;                                  // wave in block
+    __bf16 *stg = w1s + POL_HIDDEN * KP + (size_t)wib * 32 * POL_SROW; // [32][POL_SROW]
+    const int la = lane >> 4, lf = lane & 15;                          // loader role: ant la + 4 i, floats 4 lf .. 4 lf + 3
+    const int nchunks = (IN + POL_KC - 1) / POL_KC;
     for (int t = wave; t < ntiles; t += nwaves) {
         const int ant = min(t * 32 + r, M - 1); // clamped: duplicates are not written back
-        const float *row = obs + (size_t)ant * F;
+        const int rows = min(32, M - t * 32);
+        const float *tile = obs + (size_t)t * 32 * F;
         const __bf16 *wrow = w1s + r * KP + 8 * h;
         f32x16 acc;
 #pragma unroll
         for (int g = 0; g < 16; ++g) acc[g] = 0.0f;
-#pragma unroll 4
-        for (int s = 0; s < full; ++s) {
-            const int k0 = 16 * s + 8 * h;
-            const F4 lo = *reinterpret_cast<const F4 *>(row + k0);
-            const F4 hi = *reinterpret_cast<const F4 *>(row + k0 + 4);
-            bf16x8 bfrag;
+#define POL_LOAD(V, CH)                                                                                  \
+    {                                                                                                    \
+        const int k_ = POL_KC * (CH) + 4 * lf;                                                           \
+        if (POL_KC * ((CH) + 1) <= F) { /* every input of the chunk lies inside the observation rows */  \
+            _Pragma("unroll") for (int i = 0; i < 8; ++i)                                                \
+            {                                                                                            \
+                const int a = min(la + 4 * i, rows - 1);                                                 \
+                V[i] = *reinterpret_cast<const F4 *>(tile + (size_t)a * F + k_);                         \
+            }                                                                                            \
+        } else if ((CH) < nchunks) { /* end of the row, the two agent_state inputs, zero pad */          \
+            _Pragma("unroll") for (int i = 0; i < 8; ++i)                                                \
+            {                                                                                            \
+                const int a = min(la + 4 * i, rows - 1);                                                 \
+                _Pragma("unroll") for (int j = 0; j < 4; ++j)                                            \
+                {                                                                                        \
+                    const int kk = k_ + j;                                                               \
+                    V[i].v[j] = kk < F ? tile[(size_t)a * F + kk]                                        \
+                                       : (kk < IN ? agent_state[((size_t)t * 32 + a) * 2 + (kk - F)] : 0.0f); \
+                }                                                                                        \
+            }                                                                                            \
+        }                                                                                                \
+    }
+        F4 v[8], nx[8];
+        POL_LOAD(v, 0)
+        for (int c = 0; c < nchunks; ++c) {
+            POL_LOAD(nx, c + 1)
+            pol_wave_sync(); // the previous chunk's fragment reads are done
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { bfrag[j] = (__bf16)lo.v[j]; bfrag[4 + j] = (__bf16)hi.v[j]; }
-            const bf16x8 afrag = *reinterpret_cast<const bf16x8 *>(wrow + 16 * s);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag, acc, 0, 0, 0);
-        }
-        for (int s = full; s < ksteps; ++s) { // tail: end of the row, the two agent_state inputs, zero pad
-            bf16x8 bfrag;
+            for (int i = 0; i < 8; ++i) {
+                bf16x4 pk;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int k = 16 * s + 8 * h + j;
-                const float x = k < F ? row[k] : (k < IN ? agent_state[(size_t)ant * 2 + (k - F)] : 0.0f);
-                bfrag[j] = (__bf16)x;
+                for (int j = 0; j < 4; ++j) pk[j] = (__bf16)v[i].v[j];
+                *reinterpret_cast<bf16x4 *>(stg + (la + 4 * i) * POL_SROW + 4 * lf) = pk;
             }
-            const bf16x8 afrag = *reinterpret_cast<const bf16x8 *>(wrow + 16 * s);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag, acc, 0, 0, 0);
+            pol_wave_sync();
+            const int s_end = min(ksteps - (POL_KC / 16) * c, POL_KC / 16);
+            for (int s = 0; s < s_end; ++s) {
+                const bf16x8 bfrag = *reinterpret_cast<const bf16x8 *>(stg + r * POL_SROW + 16 * s + 8 * h);
+                const bf16x8 afrag = *reinterpret_cast<const bf16x8 *>(wrow + 16 * ((POL_KC / 16) * c + s));
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag, acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = nx[i];
         }
+#undef POL_LOAD
         // acc[g] = hidden[(g&3) + 8*(g>>2) + 4*h] of ant r (before bias)
         f32x16 acc2;
 #pragma unroll
@@ -138,8 +180,8 @@ hipError_t antsrl_launch_policy(const float *obs, const float *agent_state, cons
     if (ksteps > POL_MAX_KSTEPS || M < 1 || F < 1) return hipErrorInvalidValue;
     const int ntiles = (M + 31) / 32;
     int blocks = (ntiles + 3) / 4;
-    if (blocks > 256 * 4) blocks = 256 * 4; // tiles are looped; 4 workgroups per CU
-    const size_t lds = (size_t)POL_HIDDEN * (16 * ksteps + 8) * 2;
+    if (blocks > 256 * 3) blocks = 256 * 3; // tiles are looped; 3 workgroups (41 KiB of LDS each) per CU, one round
+    const size_t lds = (size_t)POL_HIDDEN * (16 * ksteps + 8) * 2 + 4 * 32 * (size_t)POL_SROW * 2; // W1 + 4 wave tiles
     hipLaunchKernelGGL(k_policy_mlp, dim3(blocks), dim3(256), lds, st, obs, agent_state, w1, b1, w2, b2, w3, b3, rot,
                        ph, logits, M, F, ksteps);
     return hipGetLastError();
