@@ -126,6 +126,18 @@ __device__ __forceinline__ void store_stream(float4 *dst, const float4 &v)
     __builtin_nontemporal_store(stream_f4{v.x, v.y, v.z, v.w}, reinterpret_cast<stream_f4 *>(dst));
 }
 
+// The smallest double T with sqrt(T) >= r, so that  sqrt(d2) < r  <=>  d2 < T  exactly (sqrt is correctly
+// rounded and monotone): the per-cell rock test (circle_obstacles.py via RL_api.py:132-135,
+// `dist < radius` on a float64 norm) then needs no square root.  r <= 0 never matches (T = 0).
+__device__ __forceinline__ double sqrt_lt_threshold(double r)
+{
+    if (!(r > 0.0)) return 0.0;
+    double t = r * r;
+    for (int it = 0; it < 8 && sqrt(t) >= r; ++it) t = __longlong_as_double(__double_as_longlong(t) - 1); // step down
+    for (int it = 0; it < 16 && sqrt(t) < r; ++it) t = __longlong_as_double(__double_as_longlong(t) + 1); // first t with sqrt(t) >= r
+    return t;
+}
+
 __host__ __device__ __forceinline__ size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 // ===================================================================================
@@ -193,7 +205,7 @@ __host__ __device__ __forceinline__ ActOff act_offsets(int N, int PP, int words,
         o.area = take(4 * (size_t)words);
     }
     o.mask = take((size_t)PP);
-    o.rock = take(24 * (size_t)(R > 0 ? R : 1));
+    o.rock = take(32 * (size_t)(R > 0 ? R : 1));
     const size_t stride = ((size_t)PP * K + 3 + 3) / 4 * 4; // row + up to 3 floats of misalignment
     const size_t hash_b = update_scratch_bytes(HT, R, nwaves), stage_b = 4 * (size_t)nwaves * stride;
     o.uni = take(hash_b > stage_b ? hash_b : stage_b);
@@ -341,9 +353,11 @@ k_act(const KP p, const int8_t *__restrict__ rotation, const int8_t *__restrict_
         L.t_mask[q] = p.has_mask ? p.mask[q] : (uint8_t)1;
     }
     for (int q = tid; q < R; q += T) {
-        L.rock[3 * q + 0] = p.s.rock_cx[(size_t)e * R + q];
-        L.rock[3 * q + 1] = p.s.rock_cy[(size_t)e * R + q];
-        L.rock[3 * q + 2] = p.s.rock_r[(size_t)e * R + q];
+        const double rad = p.s.rock_r[(size_t)e * R + q];
+        L.rock[4 * q + 0] = p.s.rock_cx[(size_t)e * R + q];
+        L.rock[4 * q + 1] = p.s.rock_cy[(size_t)e * R + q];
+        L.rock[4 * q + 2] = rad;
+        L.rock[4 * q + 3] = sqrt_lt_threshold(rad);
     }
     if (do_step)
         for (int h = tid; h < p.HT; h += T) {
@@ -457,8 +471,8 @@ k_act(const KP p, const int8_t *__restrict__ rotation, const int8_t *__restrict_
         if (R > 0) {
             const bool border = xf - margin < 0 || yf - margin < 0 || xf + margin >= W || yf + margin >= H;
             for (int q = 0; q < R; ++q) {
-                const double dx = L.rock[3 * q + 0] - xf, dy = L.rock[3 * q + 1] - yf;
-                const double rr = L.rock[3 * q + 2] + margin;
+                const double dx = L.rock[4 * q + 0] - xf, dy = L.rock[4 * q + 1] - yf;
+                const double rr = L.rock[4 * q + 2] + margin;
                 if (border || dx * dx + dy * dy < rr * rr) rm |= 1u << q;
             }
         }
@@ -550,7 +564,7 @@ k_act(const KP p, const int8_t *__restrict__ rotation, const int8_t *__restrict_
                 const bool real = (i0 + u < i_end) && lane < PP; // clamped duplicates must not count twice
                 const uint32_t cl = c_cell[u];
                 const uint32_t wd = cl >> 5, bit = 1u << (cl & 31);
-                if (real && explore && !(L.b_old[wd] & bit)) { // reward_custom.py:19,22 (mask ignored)
+                if (real && explore && !abl_explore && !(L.b_old[wd] & bit)) { // reward_custom.py:19,22 (mask ignored)
                     atomicAdd(&L.cnt[i], 1u);
                     atomicOr(&g_expl[wd], bit); // marks go straight to HBM: every count uses the LDS copy of the pre-step map
                 }
@@ -577,9 +591,9 @@ k_act(const KP p, const int8_t *__restrict__ rotation, const int8_t *__restrict_
                     while (rm) {
                         const int r = __builtin_ctz(rm);
                         rm &= rm - 1;
-                        const double vx = (double)c_ix[u] - L.rock[3 * r + 0];
-                        const double vy = (double)c_iy[u] - L.rock[3 * r + 1];
-                        any |= sqrt(vx * vx + vy * vy) < L.rock[3 * r + 2];
+                        const double vx = (double)c_ix[u] - L.rock[4 * r + 0];
+                        const double vy = (double)c_iy[u] - L.rock[4 * r + 1];
+                        any |= vx * vx + vy * vy < L.rock[4 * r + 3]; // == sqrt(d2) < radius, see sqrt_lt_threshold
                     }
                     v_rock = any ? 1.0f : 0.0f;
                 }
@@ -718,9 +732,9 @@ k_act(const KP p, const int8_t *__restrict__ rotation, const int8_t *__restrict_
                         while (rm) {
                             const int r = __builtin_ctz(rm);
                             rm &= rm - 1;
-                            const double vx = (double)ixv[u] - L.rock[3 * r + 0];
-                            const double vy = (double)iyv[u] - L.rock[3 * r + 1];
-                            any |= sqrt(vx * vx + vy * vy) < L.rock[3 * r + 2];
+                            const double vx = (double)ixv[u] - L.rock[4 * r + 0];
+                            const double vy = (double)iyv[u] - L.rock[4 * r + 1];
+                            any |= vx * vx + vy * vy < L.rock[4 * r + 3]; // == sqrt(d2) < radius
                         }
                         v_rock = any ? 1.0f : 0.0f;
                     }
@@ -1917,7 +1931,7 @@ static hipError_t launch_act_c(const KP &p, const int8_t *rot, const int8_t *ph,
     const uint32_t row = (uint32_t)p.PP * p.K;
     // the pipelined loop: one pass (PP <= 64), row of 8..508 floats, observation wanted, no ablation
     const bool fast = C == 2 && layout != LAYOUT_GENERIC && p.PP <= 64 && row >= 8 && row <= 508 && obs &&
-                      !(flags & 0xF00);
+                      !(flags & 0x700); // (ACT_ABL_NO_EXPLORE is honoured by the pipelined loop too)
 #define ACT_GO(ST, LY, FA) \
     return launch_act_k<C, ST, LY, FA>(p, pl, rot, ph, cur, obs, agent_state, reward, done, flags, jitter, out_buf, st)
     if (C == 2 && layout != LAYOUT_GENERIC) {
