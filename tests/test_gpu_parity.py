@@ -246,6 +246,46 @@ def test_full_bench_batch_sampled_envs_vs_oracle(torch_mod):
     assert (_cpu(env.read_state(cm.S_TIMESTEP)) == steps + 1).all()
 
 
+def test_full_bench_batch_long_horizon_vs_oracle(torch_mod):
+    """300 steps of the full config-3 batch (scaled pheromone units re-used across hundreds of updates,
+    ants that have spread, picked food up and brought it home); three sampled environments follow the
+    oracle step for step (reward every step, observation and state every 50)."""
+    from antsrl_amd import config as cm
+    from antsrl_amd.batched import BatchedAntsEnv
+    from antsrl_amd.synth import synth_init
+    from oracle.oracle import Oracle
+    E, N, steps, pick = 1024, 512, 300, [3, 600, 1020]
+    cfg = cm.make_cfg(E, N, 256, 256, n_rocks=8, deposit_strength=256.0)
+    cfg_s = cm.make_cfg(len(pick), N, 256, 256, n_rocks=8, deposit_strength=256.0)
+    init = synth_init(cfg, seed=4321)
+    orc = Oracle(cfg_s, {k: np.ascontiguousarray(v[pick]) for k, v in init.items()}, n_threads=3)
+    env = BatchedAntsEnv(cfg)
+    env.reset(init)
+    rng = np.random.default_rng(2024)
+    for t in range(steps):
+        rot = rng.integers(-1, 2, (E, N), dtype=np.int8)
+        ph = rng.integers(0, 3, (E, N), dtype=np.int8)
+        jit = rng.random((E, N))
+        obs, ast, rew, done = env.step_update(rot, ph, jit)
+        o_obs, o_ast, o_rew, o_done = orc.step(rot[pick], ph[pick])
+        orc.update(jit[pick])
+        np.testing.assert_array_equal(_cpu(rew[pick]), o_rew.astype(np.float32), err_msg="step %d" % t)
+        if t % 50 == 49 or t == steps - 1:
+            go = _cpu(obs[pick])
+            for j in range(len(pick)):
+                check_obs(cfg_s, go[j], o_obs[j], "long run step %d env %d" % (t, pick[j]))
+            np.testing.assert_array_equal(_cpu(ast[pick]), o_ast.astype(np.float32))
+            xyt = _cpu(env.read_state(cm.S_ANTS_XYT))[pick]
+            np.testing.assert_allclose(xyt, orc.ants_xyt, rtol=0, atol=XY_ATOL, err_msg="step %d" % t)
+            np.testing.assert_array_equal(_cpu(env.read_state(cm.S_HOLDING))[pick], orc.holding)
+    np.testing.assert_array_equal(_cpu(env.read_state(cm.S_FOOD))[pick], orc.food)
+    np.testing.assert_array_equal(_cpu(env.read_state(cm.S_EXPLORED))[pick], orc.explored)
+    np.testing.assert_array_equal(_cpu(env.read_state(cm.S_ANTHILL_FOOD))[pick], orc.anthill_food)
+    np.testing.assert_allclose(_cpu(env.read_state(cm.S_ROCK_CENTERS))[pick], orc.rock_centers, rtol=0, atol=XY_ATOL)
+    assert phero_close(_cpu(env.read_state(cm.S_PHERO))[pick], orc.phero).all()
+    assert orc.anthill_food.sum() > 0 and (orc.holding > 0).any(), "the run should exercise pickup and delivery"
+
+
 def test_config2_vs_oracle_injected_jitter(torch_mod):
     from antsrl_amd.config import make_cfg
     from antsrl_amd.synth import synth_init
