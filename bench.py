@@ -234,7 +234,8 @@ def main():
             if cm.uses_scaled_units(cfg):
                 kern.pop("sweep")  # scaled pheromone units: no sweep kernel is launched at all
             dom = max(kern, key=kern.get)
-            names = dict(sweep="k_sweep0" if cfg.filter_radius == 0 else "k_sweep_march", act="k_act", update="k_update")
+            names = dict(sweep="k_sweep0" if cfg.filter_radius == 0 else "k_sweep_march", act="k_act",
+                         update="k_update_one" if cfg.n_ants <= 1024 else "k_update")
             achieved = ab[dom] * E / (kern[dom] * 1e-3) / 1e9
             traffic = None
             tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.config)
