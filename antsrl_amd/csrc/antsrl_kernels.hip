@@ -649,8 +649,11 @@ k_act(const KP p, const int8_t *__restrict__ rotation, const int8_t *__restrict_
         }
 #undef ACT_FETCH
     }
+    // A perception of more than 64 cells takes several passes over ONE staging row per wave, so such a
+    // wave works on a single ant at a time (the second slot of the group stays empty).
+    const int ustep = npass > 1 ? 1 : ACT_UNROLL;
     if (!FAST)
-    for (int i0 = wave * ACT_UNROLL; i0 < ((flags & ACT_ABL_NO_ITEMS) ? 0 : N); i0 += nwaves * ACT_UNROLL) {
+    for (int i0 = wave * ustep; i0 < ((flags & ACT_ABL_NO_ITEMS) ? 0 : N); i0 += nwaves * ustep) {
         for (int pass = 0; pass < npass; ++pass) {
             const int q = pass * 64 + lane;
             const bool lane_on = q < PP;
@@ -664,7 +667,7 @@ k_act(const KP p, const int8_t *__restrict__ rotation, const int8_t *__restrict_
 #pragma unroll
             for (int u = 0; u < ACT_UNROLL; ++u) {
                 const int i = i0 + u;
-                valid[u] = lane_on && i < N;
+                valid[u] = lane_on && i < N && u < ustep;
                 const AntFrame fr = L.frame[i < N ? i : 0]; // wave-uniform address: LDS broadcast
                 const double rx = fr.ct * of.px - fr.st * of.py; // RL_api.py:110-111
                 const double ry = fr.st * of.px + fr.ct * of.py;
@@ -708,7 +711,7 @@ k_act(const KP p, const int8_t *__restrict__ rotation, const int8_t *__restrict_
 #pragma unroll
             for (int u = 0; u < ACT_UNROLL; ++u) {
                 const int i = i0 + u;
-                if (i >= N) break; // wave-uniform
+                if (i >= N || u >= ustep) break; // wave-uniform
                 const uint32_t cl = cell[u];
                 const uint32_t wd = cl >> 5, bit = 1u << (cl & 31);
                 if (valid[u] && explore && !abl_explore && !(L.b_old[wd] & bit)) { // reward_custom.py:19,22

@@ -362,6 +362,23 @@ def test_small_and_odd_shapes(torch_mod):
         _compare_with_oracle(torch_mod, cfg, init, steps=8, seed=2, jitter_mode="injected")
 
 
+def test_large_and_ragged_ant_counts(torch_mod):
+    """Ant counts on either side of the kernels' one-ant-per-thread fast paths: N > 1024 (k_update's
+    per-phase loops, three ants per thread in k_act), an odd N just under 1024 (1024-thread
+    k_update_one, odd tail of a wave's run in the pipelined perception loop), and an 11x11 perception
+    (two passes of the generic loop)."""
+    from antsrl_amd import config as cm
+    from antsrl_amd.synth import synth_init
+    for (E, N, W, H, kw, steps) in [
+        (1, 1500, 64, 64, dict(n_rocks=2, deposit_strength=256.0), 5),
+        (2, 1023, 96, 80, dict(n_rocks=3, deposit_strength=256.0), 5),
+        (2, 300, 64, 64, dict(perception_radius=5, mask=None), 4),
+    ]:
+        cfg = cm.make_cfg(E, N, W, H, **kw)
+        init = synth_init(cfg, seed=9, n_food_discs=5, food_rmin=2, food_rmax=5)
+        _compare_with_oracle(torch_mod, cfg, init, steps=steps, seed=4, jitter_mode="injected")
+
+
 def test_known_answers(torch_mod):
     """Hand-derived cases for the semantics catalogued in SURVEY.md §8(a)."""
     from antsrl_amd import config as cm
