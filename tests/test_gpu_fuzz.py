@@ -1,0 +1,79 @@
+"""Randomised configurations against the oracle: perception radius 1..7 (one and several passes), random
+masks, channel lists in any order with repeats (generic layout), 1..4 pheromone channels, 0..4 rocks,
+every reward kind, diffusion filters of radius 0..2 in both pheromone modes, ragged grids and ant
+counts, forward shifts.  Each case is a few steps of step + update with injected wall-jitter draws."""
+import numpy as np
+import pytest
+
+from test_gpu_parity import _compare_with_oracle, _cpu, check_obs, torch_mod  # noqa: F401  (the parity suite's checks and fixture)
+
+pytestmark = pytest.mark.gpu
+
+
+def _random_case(rng):
+    from antsrl_amd import config as cm
+    E = int(rng.integers(1, 4))
+    N = int(rng.choice([1, 7, 64, 65, 130, 257, 600, 1025, 1100]))
+    W, H = int(rng.integers(12, 90)), int(rng.integers(12, 90))
+    r = int(rng.integers(1, 8))
+    n_phero = int(rng.choice([2, 2, 2, 1, 3, 4]))
+    n_rocks = int(rng.integers(0, 5))
+    kinds_pool = [cm.CH_ANTS, cm.CH_ANTHILL, cm.CH_WALLS, cm.CH_FOOD] + [cm.CH_PHERO] * 2 + ([cm.CH_ROCKS] if n_rocks else [])
+    K = int(rng.integers(1, 10))
+    channels = []
+    for _ in range(K):
+        k = int(rng.choice(kinds_pool))
+        channels.append((k, int(rng.integers(0, n_phero)) if k == cm.CH_PHERO else 0))
+    if rng.random() < 0.35:
+        channels = None  # the generator's default layout
+    mask = None if rng.random() < 0.3 else (rng.random((2 * r + 1, 2 * r + 1)) < 0.8)
+    fr = int(rng.choice([0, 0, 1, 2]))
+    if fr == 0:
+        filt = np.array([[float(rng.choice([0.999, 0.9, 1.0]))]])
+    else:
+        filt = rng.random((2 * fr + 1, 2 * fr + 1))
+        filt = filt / filt.sum() * float(rng.choice([0.999, 0.95]))
+    kw = dict(n_phero=n_phero, n_rocks=n_rocks, mask=mask, perception_radius=r, channels=channels,
+              fwd_delta=float(rng.choice([0.0, 4.0, 2.5])), deposit_strength=float(rng.choice([1.0, 256.0])),
+              filt=filt, reward_kind=int(rng.integers(0, 4)), fct_explore_holding=float(rng.choice([0.0, 0.5])),
+              phero_mode=int(rng.integers(0, 2)), max_time=int(rng.choice([3, 2000])),
+              delta=float(rng.choice([1.1, 1.1, 1.0, 1.37])), max_speed=float(rng.choice([1.0, 2.5])),
+              max_hold=float(rng.choice([5.0, 2.0])))
+    if channels is not None and not any(k == cm.CH_PHERO for k, _ in channels) and rng.random() < 0.5:
+        kw["phero_max_val"] = None  # Pheromone(max_val=None): legal as long as no pheromone is perceived
+    return E, N, W, H, kw
+
+
+@pytest.mark.parametrize("seed", range(64))
+def test_random_configuration_vs_oracle(torch_mod, seed):
+    from antsrl_amd import config as cm
+    from antsrl_amd.batched import BatchedAntsEnv
+    from antsrl_amd.synth import synth_init
+    from oracle.oracle import Oracle
+    rng = np.random.default_rng(1000 + seed)
+    E, N, W, H, kw = _random_case(rng)
+    cfg = cm.make_cfg(E, N, W, H, **kw)
+    init = synth_init(cfg, seed=seed, n_food_discs=4, food_rmin=1, food_rmax=4, wall_density=0.08)
+    if cfg.n_phero == 2:
+        _compare_with_oracle(torch_mod, cfg, init, steps=5, seed=seed, jitter_mode="injected")
+        return
+    # pheromone actions need exactly two channels (ants.py:89-96): rotation only, activation set directly
+    env, orc = BatchedAntsEnv(cfg), Oracle(cfg, init)
+    env.reset(init)
+    act = rng.choice([0.0, 10.0], size=(E, N, cfg.n_phero)).astype(np.float32)
+    env.set_activation(act)
+    orc.set_activation(act)
+    for t in range(5):
+        rot = rng.integers(-1, 2, (E, N), dtype=np.int8)
+        jit = rng.random((E, N))
+        obs, ast, rew, done = env.step(rot, None)
+        o_obs, o_ast, o_rew, o_done = orc.step(rot, None)
+        for e in range(E):
+            check_obs(cfg, _cpu(obs)[e], o_obs[e], "seed %d step %d env %d" % (seed, t, e))
+        np.testing.assert_array_equal(_cpu(rew), o_rew.astype(np.float32))
+        np.testing.assert_array_equal(_cpu(done), o_done)
+        env.update(jit)
+        orc.update(jit)
+    from helpers import phero_close
+    assert phero_close(_cpu(env.read_state(cm.S_PHERO)), orc.phero, threshold=cfg.phero_threshold).all()
+    np.testing.assert_allclose(_cpu(env.read_state(cm.S_ANTS_XYT)), orc.ants_xyt, rtol=0, atol=1e-9)
