@@ -77,3 +77,54 @@ def test_random_configuration_vs_oracle(torch_mod, seed):
     from helpers import phero_close
     assert phero_close(_cpu(env.read_state(cm.S_PHERO)), orc.phero, threshold=cfg.phero_threshold).all()
     np.testing.assert_allclose(_cpu(env.read_state(cm.S_ANTS_XYT)), orc.ants_xyt, rtol=0, atol=1e-9)
+
+
+@pytest.mark.parametrize("seed", range(100, 124))
+def test_random_configuration_fused_calls_and_standalone_observation(torch_mod, seed):
+    """The same random configurations driven the way main.py does: antsrl_step_update (one call per
+    step), a standalone observation before the first step and after some updates (main.py:88), and a
+    step without pheromone actions."""
+    from antsrl_amd import config as cm
+    from antsrl_amd.batched import BatchedAntsEnv
+    from antsrl_amd.synth import synth_init
+    from oracle.oracle import Oracle
+    rng = np.random.default_rng(1000 + seed)
+    E, N, W, H, kw = _random_case(rng)
+    kw["n_phero"] = 2
+    if kw["channels"] is not None:
+        kw["channels"] = [(k, a % 2) for k, a in kw["channels"]]
+    cfg = cm.make_cfg(E, N, W, H, **kw)
+    init = synth_init(cfg, seed=seed, n_food_discs=4, food_rmin=1, food_rmax=4, wall_density=0.08)
+    env, orc = BatchedAntsEnv(cfg), Oracle(cfg, init)
+    env.reset(init)
+
+    def same_obs(got, want, ctx):
+        g = _cpu(got)
+        for e in range(E):
+            check_obs(cfg, g[e], want[e], "seed %d %s env %d" % (seed, ctx, e))
+
+    obs, ast, rew = env.observe()
+    o_obs, o_ast, o_rew = orc.observe()
+    same_obs(obs, o_obs, "first observation")
+    np.testing.assert_array_equal(_cpu(rew), o_rew.astype(np.float32))
+    for t in range(6):
+        rot = rng.integers(-1, 2, (E, N), dtype=np.int8)
+        ph = rng.integers(0, 3, (E, N), dtype=np.int8) if t != 3 else None
+        jit = rng.random((E, N))
+        obs, ast, rew, done = env.step_update(rot, ph, jit)
+        o_obs, o_ast, o_rew, o_done = orc.step(rot, ph)
+        orc.update(jit)
+        same_obs(obs, o_obs, "step %d" % t)
+        np.testing.assert_array_equal(_cpu(ast), o_ast.astype(np.float32))
+        np.testing.assert_array_equal(_cpu(rew), o_rew.astype(np.float32))
+        np.testing.assert_array_equal(_cpu(done), o_done)
+        if t in (1, 4):
+            obs, ast, rew = env.observe()
+            o_obs, o_ast, o_rew = orc.observe()
+            same_obs(obs, o_obs, "observation after update %d" % t)
+            np.testing.assert_array_equal(_cpu(rew), o_rew.astype(np.float32))
+    from helpers import phero_close
+    assert phero_close(_cpu(env.read_state(cm.S_PHERO)), orc.phero, threshold=cfg.phero_threshold).all()
+    np.testing.assert_allclose(_cpu(env.read_state(cm.S_ANTS_XYT)), orc.ants_xyt, rtol=0, atol=1e-9)
+    np.testing.assert_array_equal(_cpu(env.read_state(cm.S_FOOD)), orc.food)
+    np.testing.assert_array_equal(_cpu(env.read_state(cm.S_ANTHILL_FOOD)), orc.anthill_food)
