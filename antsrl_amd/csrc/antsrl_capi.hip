@@ -181,6 +181,36 @@ static void fill_kp(const AntsCfg *c, KP *p)
                 p->ftap[(b * S + a) * 2 + 1] = (float)(f - (double)hi);
             }
     }
+    {
+        // Rank-1 test: F == u v^T / F[i0][j0] around the largest tap, to 4 ulp of the largest tap.  Then the
+        // stencil runs as a pass across the lanes followed by a pass along the march (2 x S taps instead of
+        // S x S).  The taps u[a] * v[b] differ from F[a][b] by ~1e-16 relative: far inside the fp32 grid's
+        // rounding, and unbiased like the hi + lo split of the full filter.
+        const int S = 2 * c->filter_radius + 1;
+        p->filter_sep = 0;
+        if (S > 1 && !getenv("ANTSRL_NO_SEPARABLE")) {
+            int i0 = 0, j0 = 0;
+            double big = 0.0;
+            for (int a = 0; a < S; ++a)
+                for (int b = 0; b < S; ++b)
+                    if (fabs(c->filter[a * S + b]) > big) { big = fabs(c->filter[a * S + b]); i0 = a; j0 = b; }
+            bool sep = big > 0.0;
+            double u[2 * ANTSRL_MAX_FILTER_RADIUS + 1], v[2 * ANTSRL_MAX_FILTER_RADIUS + 1];
+            for (int a = 0; a < S && sep; ++a) u[a] = c->filter[a * S + j0];
+            for (int b = 0; b < S && sep; ++b) v[b] = c->filter[i0 * S + b] / c->filter[i0 * S + j0];
+            for (int a = 0; a < S && sep; ++a)
+                for (int b = 0; b < S; ++b)
+                    if (fabs(u[a] * v[b] - c->filter[a * S + b]) > 1e-15 * big) sep = false;
+            if (sep) {
+                p->filter_sep = 1;
+                for (int k = 0; k < S; ++k) {
+                    const float uh = (float)u[k], vh = (float)v[k];
+                    p->fsep_u[2 * k] = uh; p->fsep_u[2 * k + 1] = (float)(u[k] - (double)uh);
+                    p->fsep_v[2 * k] = vh; p->fsep_v[2 * k + 1] = (float)(v[k] - (double)vh);
+                }
+            }
+        }
+    }
     p->rng_seed = c->rng_seed;
     p->scaled = use_scaled(c) ? 1 : 0;
     p->g_now = p->g_dep = p->inv_g_dep = 1.0;

@@ -60,6 +60,10 @@ struct KP {
     // stencil runs in fp32 FMAs without the systematic per-step bias a rounded tap would add
     // layout [b][a]{hi,lo} (b = tap column, a = tap row) so one column's taps are contiguous
     float ftap[2 * ANTSRL_MAX_FILTER_TAPS];
+    // Rank-1 filters F[a][b] = u[a] * v[b] (a Gaussian, the reference's 3x3 when DIFFUSE_FACTOR = 0 ...):
+    // {hi, lo} pairs of u (tap row index a: the marching direction) and v (tap column index b: across lanes)
+    int32_t filter_sep, _pad2;
+    float fsep_u[2 * (2 * ANTSRL_MAX_FILTER_RADIUS + 1)], fsep_v[2 * (2 * ANTSRL_MAX_FILTER_RADIUS + 1)];
 };
 
 // k_act flags

@@ -1461,7 +1461,20 @@ __global__ void __launch_bounds__(256) k_phero_renorm(const KP p)
 //   out[x,y] = sum_{a,b} F[a,b] * in[x-a+R, y-b+R]      (convolve2d 'same', zero fill)
 // Arithmetic: fp32 FMAs with the taps split hi+lo (see KP::ftap) — unbiased to ~1e-15 per step.
 // Loop order b -> a -> row keeps only one tap column (2S scalars) live at a time.
-template <int C, int R>
+// lane i <- lane i - 1 / lane i + 1 across the whole wave (zero shifted in at the ends)
+__device__ __forceinline__ float wave_shr1(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float wave_shl1(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xF, 0xF, true));
+}
+
+// SEP: the filter is rank-1, F[a][b] = u[a] v[b] (KP::fsep_u / fsep_v): each input row is first
+// convolved across the lanes with v (S shuffles), the result feeds the S running output rows with u —
+// 4 S FMAs per input value instead of 2 S^2.
+template <int C, int R, bool SEP>
 __global__ void __launch_bounds__(256)
 k_sweep_march(const KP p, const float *__restrict__ in, float *__restrict__ out, const int seg_rows)
 {
@@ -1473,7 +1486,11 @@ k_sweep_march(const KP p, const float *__restrict__ in, float *__restrict__ out,
     // they are used: ~100 wave-uniform scalars do not fit the SGPR file — as kernel arguments the
     // compiler hoists them out of the march and spills them through v_writelane/v_readlane.
     __shared__ float taps[2 * ANTSRL_MAX_FILTER_TAPS];
-    if (threadIdx.x < 2 * S * S) taps[threadIdx.x] = p.ftap[threadIdx.x];
+    if (!SEP && threadIdx.x < 2 * S * S) taps[threadIdx.x] = p.ftap[threadIdx.x];
+    if (SEP && threadIdx.x < 2 * S) {
+        taps[threadIdx.x] = p.fsep_u[threadIdx.x];
+        taps[2 * S + threadIdx.x] = p.fsep_v[threadIdx.x];
+    }
     __syncthreads();
     if (strip * OUTW >= H) return; // whole wave (no further barriers)
     const int y = strip * OUTW - R + lane;
@@ -1543,6 +1560,40 @@ k_sweep_march(const KP p, const float *__restrict__ in, float *__restrict__ out,
         // ---- accumulate: input row s feeds output row j = s + a (x = xi0 + s + a - R).
         //      The tap-column loop is a REAL loop (not unrolled): only one column's 2S taps are live,
         //      so nothing tempts the compiler to hoist ~100 scalars out of the march and spill them.
+        if (SEP) {
+            float hrow[S][C]; // input row s convolved across the lanes with v
+            // neighbours by whole-wave DPP shifts of one lane (v_mov_b32_dpp wave_shr:1 / wave_shl:1, a VALU
+            // move) instead of ds_bpermute: the LDS pipe stays out of the inner loop
+#pragma unroll
+            for (int s = 0; s < S; ++s)
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    float h = fmaf(taps[2 * S + 2 * R], v[s][c], 0.0f);
+                    h = fmaf(taps[2 * S + 2 * R + 1], v[s][c], h);
+                    float up = v[s][c], dn = v[s][c]; // up: value of lane - d, dn: value of lane + d
+#pragma unroll
+                    for (int d = 1; d <= R; ++d) {
+                        up = wave_shr1(up);
+                        dn = wave_shl1(dn);
+                        h = fmaf(taps[2 * S + 2 * (R + d)], up, h);
+                        h = fmaf(taps[2 * S + 2 * (R + d) + 1], up, h);
+                        h = fmaf(taps[2 * S + 2 * (R - d)], dn, h);
+                        h = fmaf(taps[2 * S + 2 * (R - d) + 1], dn, h);
+                    }
+                    hrow[s][c] = h;
+                }
+#pragma unroll
+            for (int a = 0; a < S; ++a) {
+                const float uh = taps[2 * a], ul = taps[2 * a + 1];
+#pragma unroll
+                for (int s = 0; s < S; ++s)
+#pragma unroll
+                    for (int c = 0; c < C; ++c) {
+                        acc[s + a][c] = fmaf(uh, hrow[s][c], acc[s + a][c]);
+                        acc[s + a][c] = fmaf(ul, hrow[s][c], acc[s + a][c]);
+                    }
+            }
+        } else
 #pragma unroll 1
         for (int b = 0; b < S; ++b) {
             float sh[S][C]; // sh[s] = in[xi0+s][y - b + R]
@@ -1993,9 +2044,13 @@ static hipError_t launch_sweep_c(const KP &p, int cur, hipStream_t st)
         while ((long long)p.E * strips * nseg < 16 * 1024 && p.W / (nseg * 2) >= 64) nseg *= 2;
         const int seg_rows = (p.W + nseg - 1) / nseg;
         dim3 grid((strips + 3) / 4, p.E, (p.W + seg_rows - 1) / seg_rows);
-        if (fr == 1) hipLaunchKernelGGL((k_sweep_march<C, 1>), grid, dim3(256), 0, st, p, in, out, seg_rows);
-        else if (fr == 2) hipLaunchKernelGGL((k_sweep_march<C, 2>), grid, dim3(256), 0, st, p, in, out, seg_rows);
-        else hipLaunchKernelGGL((k_sweep_march<C, 3>), grid, dim3(256), 0, st, p, in, out, seg_rows);
+        if (p.filter_sep) {
+            if (fr == 1) hipLaunchKernelGGL((k_sweep_march<C, 1, true>), grid, dim3(256), 0, st, p, in, out, seg_rows);
+            else if (fr == 2) hipLaunchKernelGGL((k_sweep_march<C, 2, true>), grid, dim3(256), 0, st, p, in, out, seg_rows);
+            else hipLaunchKernelGGL((k_sweep_march<C, 3, true>), grid, dim3(256), 0, st, p, in, out, seg_rows);
+        } else if (fr == 1) hipLaunchKernelGGL((k_sweep_march<C, 1, false>), grid, dim3(256), 0, st, p, in, out, seg_rows);
+        else if (fr == 2) hipLaunchKernelGGL((k_sweep_march<C, 2, false>), grid, dim3(256), 0, st, p, in, out, seg_rows);
+        else hipLaunchKernelGGL((k_sweep_march<C, 3, false>), grid, dim3(256), 0, st, p, in, out, seg_rows);
     } else { // LDS-tiled float64 reference variant (A/B and cross-check: ANTSRL_SWEEP_TILED=1)
         const int fr = p.filter_radius;
         const size_t lds = (size_t)(SW_TX + 2 * fr) * (SW_TY + 2 * fr) * C * sizeof(float);

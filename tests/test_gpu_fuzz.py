@@ -32,6 +32,8 @@ def _random_case(rng):
         filt = np.array([[float(rng.choice([0.999, 0.9, 1.0]))]])
     else:
         filt = rng.random((2 * fr + 1, 2 * fr + 1))
+        if rng.random() < 0.4:  # rank-1: the separable form of the stencil
+            filt = np.outer(rng.random(2 * fr + 1), rng.random(2 * fr + 1))
         filt = filt / filt.sum() * float(rng.choice([0.999, 0.95]))
     kw = dict(n_phero=n_phero, n_rocks=n_rocks, mask=mask, perception_radius=r, channels=channels,
               fwd_delta=float(rng.choice([0.0, 4.0, 2.5])), deposit_strength=float(rng.choice([1.0, 256.0])),
