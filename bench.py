@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py — ant-steps/s of the AntsRL environment step loop on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c3|c2|c4]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c3|c1|c2|c4|c5]
 
 One "step" = RLApi.step + Environment.update (main.py:98 + main.py:131 of the reference) over one
 batch of E environments, through the C-ABI (antsrl_step_update).  Default workload is BASELINE.json
@@ -27,6 +27,8 @@ sys.path.insert(0, ROOT)
 
 CONFIGS = {
     # name: (E per GPU, N, W, H, R, radius-3 filter?)
+    "c1": dict(E=1, N=32, W=64, H=64, R=0, radius3=False,
+               desc="BASELINE configs[0]: the reference's own case, 1 env x 32 ants, 64x64 (step latency)"),
     "c2": dict(E=256, N=256, W=256, H=256, R=0, radius3=False,
                desc="BASELINE configs[1]: 256 envs x 256 ants, 256x256, 2 pheromone channels"),
     "c3": dict(E=1024, N=512, W=256, H=256, R=8, radius3=False,
