@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("ANTSRL_LIB") or os.path.join(os.path.dirname(os.path.
 EXPORTS = ("antsrl_abi_version", "antsrl_cfg_size", "antsrl_last_error", "antsrl_workspace_bytes", "antsrl_create",
            "antsrl_destroy", "antsrl_reset", "antsrl_generate", "antsrl_step", "antsrl_observe", "antsrl_update",
            "antsrl_step_update", "antsrl_set_timing_events", "antsrl_set_activation", "antsrl_policy_mlp", "antsrl_read_state", "antsrl_state_bytes",
-           "antsrl_debug_read_act_trace")
+           "antsrl_debug_read_act_trace", "antsrl_set_obs_format")
 
 _lib = None
 

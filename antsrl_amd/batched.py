@@ -35,7 +35,12 @@ def _ptr(t: Optional[torch.Tensor]):
 
 
 class BatchedAntsEnv:
-    def __init__(self, cfg: AntsCfg, device: Optional[torch.device] = None):
+    def __init__(self, cfg: AntsCfg, device: Optional[torch.device] = None, obs_dtype: torch.dtype = torch.float32):
+        """obs_dtype: torch.float32 (the reference's values) or torch.bfloat16 (the same values rounded
+        to nearest even: half the bytes per step; what the bf16 policy rounds its input to anyway —
+        antsrl_set_obs_format)."""
+        if obs_dtype not in (torch.float32, torch.bfloat16):
+            raise ValueError("obs_dtype must be torch.float32 or torch.bfloat16")
         if not torch.cuda.is_available():
             raise _lib.AntsrlError("BatchedAntsEnv needs an MI355X (torch.cuda.is_available() is False); "
                                    "there is no CPU fallback")
@@ -53,7 +58,9 @@ class BatchedAntsEnv:
             _lib.check(self.lib.antsrl_create(C.byref(self.cfg), C.c_void_p(self._ws_ptr), need.value,
                                               C.byref(self._h)), "create")
             E, N, P, K = cfg.n_envs, cfg.n_ants, cfg.pside, cfg.n_channels
-            self.obs = torch.empty((E, N, P, P, K), dtype=torch.float32, device=self.device)
+            self.obs = torch.empty((E, N, P, P, K), dtype=obs_dtype, device=self.device)
+            if obs_dtype == torch.bfloat16:
+                _lib.check(self.lib.antsrl_set_obs_format(self._h, 1), "set_obs_format")
             self.agent_state = torch.empty((E, N, 2), dtype=torch.float32, device=self.device)
             self.reward = torch.empty((E, N), dtype=torch.float32, device=self.device)
             self.done = torch.zeros((E,), dtype=torch.uint8, device=self.device)

@@ -41,6 +41,7 @@ struct AntsHandle {
     uint64_t episode_seed; // seed of the current episode
     int host_timestep;     // mirrors Environment.timestep (all envs step in lockstep)
     long long sweeps;      // scaled mode: updates since the units were last re-based
+    bool obs_bf16;         // observation buffers are bfloat16 (antsrl_set_obs_format)
     bool need_wall_clear;  // scaled mode: initial grid may hold pheromone on wall cells
     hipEvent_t ev[4];      // measurement hook (antsrl_set_timing_events)
     bool ev_armed;
@@ -252,7 +253,7 @@ extern "C" int antsrl_create(const AntsCfg *cfg, void *workspace, size_t workspa
     carve(cfg, &h->p.s, (unsigned char *)workspace);
     h->cur = 0; h->steps_since_update = 0; h->need_full_collect = true; h->is_reset = false;
     h->sweeps = 0; h->need_wall_clear = false;
-    h->has_gen = false; h->episode_seed = 0; h->host_timestep = 1;
+    h->has_gen = false; h->episode_seed = 0; h->host_timestep = 1; h->obs_bf16 = false;
     h->ws_bytes = need;
     h->ev_armed = false;
     if (!antsrl_act_fits(h->p)) {
@@ -307,6 +308,20 @@ extern "C" int antsrl_generate(AntsHandle *h, const AntsGen *gen, uint64_t episo
     return do_generate(h, episode_seed, (hipStream_t)stream);
 }
 
+static int bf16_unsupported()
+{
+    return fail(ANTSRL_E_UNSUPPORTED, "bfloat16 observations need 2 pheromone channels, the generator's channel order "
+                                      "([Ants, Phero0, Phero1, Anthill, Walls, Food(, Rocks)]) and a perception of at most 64 cells");
+}
+
+extern "C" int antsrl_set_obs_format(AntsHandle *h, int format)
+{
+    if (!h) return fail(ANTSRL_E_INVALID, "NULL handle");
+    if (format != ANTSRL_OBS_F32 && format != ANTSRL_OBS_BF16) return fail(ANTSRL_E_INVALID, "bad observation format %d", format);
+    h->obs_bf16 = format == ANTSRL_OBS_BF16;
+    return ANTSRL_OK;
+}
+
 static int not_reset() { return fail(ANTSRL_E_INVALID, "antsrl_reset has not been called on this handle"); }
 
 static int do_step(AntsHandle *h, const int8_t *rot, const int8_t *ph, float *obs, float *agent_state,
@@ -318,8 +333,10 @@ static int do_step(AntsHandle *h, const int8_t *rot, const int8_t *ph, float *ob
     if (h->steps_since_update > 0) h->need_full_collect = true; // dirty-cell list would be overwritten
     static const int ablate = getenv("ANTSRL_ABLATE") ? atoi(getenv("ANTSRL_ABLATE")) & ~7 : 0; // profiling only
     hipError_t e = antsrl_launch_act(h->p, rot, ph, h->cur, obs, agent_state, reward, done,
-                                     ACT_STEP | (obs ? ACT_HAS_OBS : 0) | (fused_update ? ACT_FUSED_UPDATE : 0) | ablate,
+                                     ACT_STEP | (obs ? ACT_HAS_OBS : 0) | (fused_update ? ACT_FUSED_UPDATE : 0) | ablate |
+                                         (obs && h->obs_bf16 ? ACT_OBS_BF16 : 0),
                                      jitter, h->p.scaled ? 0 : h->cur ^ 1, st);
+    if (e == hipErrorNotSupported) return bf16_unsupported();
     if (e != hipSuccess) return hip_fail(e, "step");
     h->steps_since_update++;
     return ANTSRL_OK;
@@ -379,7 +396,9 @@ extern "C" int antsrl_observe(AntsHandle *h, float *obs, float *agent_state, flo
     if (!h) return fail(ANTSRL_E_INVALID, "NULL handle");
     if (!h->is_reset) return not_reset();
     hipError_t e = antsrl_launch_act(h->p, nullptr, nullptr, h->cur, obs, agent_state, reward, nullptr,
-                                     obs ? ACT_HAS_OBS : 0, nullptr, 0, (hipStream_t)stream);
+                                     obs ? ACT_HAS_OBS | (h->obs_bf16 ? ACT_OBS_BF16 : 0) : 0, nullptr, 0,
+                                     (hipStream_t)stream);
+    if (e == hipErrorNotSupported) return bf16_unsupported();
     if (e != hipSuccess) return hip_fail(e, "observe");
     return ANTSRL_OK;
 }
@@ -454,14 +473,14 @@ extern "C" int antsrl_set_activation(AntsHandle *h, const float *act, double new
 
 hipError_t antsrl_launch_policy(const float *obs, const float *agent_state, const float *w1, const float *b1,
                                 const float *w2, const float *b2, const float *w3, const float *b3, int8_t *rot,
-                                int8_t *ph, float *logits, int M, int F, hipStream_t st);
+                                int8_t *ph, float *logits, int M, int F, hipStream_t st, bool obs_bf16);
 
 extern "C" int antsrl_policy_mlp(AntsHandle *h, const float *obs, const float *agent_state, int64_t n_ants,
                                  int32_t n_features, const float *w1, const float *b1, const float *w2,
                                  const float *b2, const float *w3, const float *b3, int8_t *rotation,
                                  int8_t *pheromone, float *logits, void *stream)
 {
-    (void)h;
+    // h may be NULL (float32 observations); a handle supplies the observation format (antsrl_set_obs_format)
     if (!obs || !agent_state || !w1 || !b1 || !w2 || !b2 || !rotation)
         return fail(ANTSRL_E_INVALID, "policy_mlp: obs, agent_state, w1, b1, w2, b2, rotation are required");
     if ((w3 == nullptr) != (b3 == nullptr) || (pheromone && !w3))
@@ -469,7 +488,7 @@ extern "C" int antsrl_policy_mlp(AntsHandle *h, const float *obs, const float *a
     if (n_ants < 1 || n_ants > 0x7fffffff || n_features < 1 || n_features + 2 > 1024)
         return fail(ANTSRL_E_INVALID, "policy_mlp: n_ants >= 1 and 1 <= n_features <= 1022");
     hipError_t e = antsrl_launch_policy(obs, agent_state, w1, b1, w2, b2, w3, b3, rotation, pheromone, logits,
-                                        (int)n_ants, n_features, (hipStream_t)stream);
+                                        (int)n_ants, n_features, (hipStream_t)stream, h && h->obs_bf16);
     if (e != hipSuccess) return hip_fail(e, "policy_mlp");
     return ANTSRL_OK;
 }

@@ -70,6 +70,7 @@ struct KP {
 #define ACT_STEP 1        // run RLApi.step's action phases before observing
 #define ACT_HAS_OBS 2     // obs pointer valid
 #define ACT_FUSED_UPDATE 4 // run Environment.update of the same step at the tail of the launch
+#define ACT_OBS_BF16 8     // `obs` is a bfloat16 tensor (antsrl_set_obs_format): same values, rounded to nearest even
 // profiling ablations (env ANTSRL_ABLATE, results are WRONG with any of them set; bench/tests never set it)
 #define ACT_ABL_NO_ITEMS 256   // skip the perception phase
 #define ACT_ABL_NO_GATHER 512  // no pheromone/food gathers

@@ -120,7 +120,14 @@ __device__ __forceinline__ void wave_lds_sync()
 // pheromone/food lines the perception gathers reuse and the ant state k_update reads next
 // (measured on c3, same box: k_act 0.340 -> 0.287 ms, k_update 0.051 -> 0.043 ms).
 typedef float stream_f4 __attribute__((ext_vector_type(4)));
+typedef uint32_t stream_u4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void store_stream(float *dst, float v) { __builtin_nontemporal_store(v, dst); }
+__device__ __forceinline__ void store_stream(uint16_t *dst, uint16_t v) { __builtin_nontemporal_store(v, dst); }
+__device__ __forceinline__ void store_stream(uint4 *dst, const uint4 &v)
+{
+    __builtin_nontemporal_store(stream_u4{v.x, v.y, v.z, v.w}, reinterpret_cast<stream_u4 *>(dst));
+}
+__device__ __forceinline__ uint16_t bf16_bits(float v) { return __builtin_bit_cast(uint16_t, (__bf16)v); } // RNE
 __device__ __forceinline__ void store_stream(float4 *dst, const float4 &v)
 {
     __builtin_nontemporal_store(stream_f4{v.x, v.y, v.z, v.w}, reinterpret_cast<stream_f4 *>(dst));
@@ -257,7 +264,7 @@ extern "C" int antsrl_debug_read_act_trace(unsigned long long *dst, int n_wg)
 // LDS carve (`ActLds`), its pointers go through scratch and every LDS access degrades to flat_*.
 // TPB = threads per workgroup (512 or 1024); 4 waves per SIMD (<= 128 VGPRs) is all the LDS plans
 // can use (capping at 80 VGPRs for a third workgroup per CU measured slower, see plan_act).
-template <int C, bool STATIC_LDS, int LAYOUT, bool FAST, int TPB>
+template <int C, bool STATIC_LDS, int LAYOUT, bool FAST, int TPB, bool OBS16 = false>
 __global__ void __launch_bounds__(TPB, 4)
 k_act(const KP p, const int8_t *__restrict__ rotation, const int8_t *__restrict__ phero_act, const int cur,
       float *__restrict__ obs, float *__restrict__ agent_state, float *__restrict__ reward,
@@ -581,6 +588,10 @@ k_act(const KP p, const int8_t *__restrict__ rotation, const int8_t *__restrict_
                 float *dst = obs_env + (size_t)i * row;
                 const uint32_t mis = (uint32_t)(((uintptr_t)dst >> 2) & 3);
                 float *o = stage + mis + qK;
+                // bfloat16 observations: the same staging and copy-out on 2-byte elements (8 per 16 bytes)
+                uint16_t *dst16 = reinterpret_cast<uint16_t *>(obs) + ((size_t)e * N + (size_t)i) * row;
+                const uint32_t mis16 = (uint32_t)(((uintptr_t)dst16 >> 1) & 7);
+                uint16_t *o16 = reinterpret_cast<uint16_t *>(stage) + mis16 + qK;
                 const float v_ants = (L.b_pres[wd] & bit) ? 1.0f : 0.0f;  // :142
                 const float v_area = (area[wd] & bit) ? 1.0f : 0.0f;       // :130-131
                 const float v_wall = (walls[wd] & bit) ? 1.0f : 0.0f;      // :128-129
@@ -598,7 +609,12 @@ k_act(const KP p, const int8_t *__restrict__ rotation, const int8_t *__restrict_
                     v_rock = any ? 1.0f : 0.0f;
                 }
                 const bool m = mask_q; // RL_api.py:147-148: mask*(p+1)-1 == -1 on masked cells
-                if (LAYOUT == LAYOUT_DEFAULT || LAYOUT == LAYOUT_DEFAULT_ROCKS) {
+                if (OBS16) { // (only instantiated for the two default layouts)
+                    o16[0] = bf16_bits(m ? v_ants : -1.0f); o16[1] = bf16_bits(m ? pvs[0] : -1.0f);
+                    o16[2] = bf16_bits(m ? pvs[C - 1] : -1.0f); o16[3] = bf16_bits(m ? v_area : -1.0f);
+                    o16[4] = bf16_bits(m ? v_wall : -1.0f); o16[5] = bf16_bits(m ? c_fd[u] : -1.0f);
+                    if (LAYOUT == LAYOUT_DEFAULT_ROCKS) o16[6] = bf16_bits(m ? v_rock : -1.0f);
+                } else if (LAYOUT == LAYOUT_DEFAULT || LAYOUT == LAYOUT_DEFAULT_ROCKS) {
                     o[0] = m ? v_ants : -1.0f; o[1] = m ? pvs[0] : -1.0f; o[2] = m ? pvs[C - 1] : -1.0f;
                     o[3] = m ? v_area : -1.0f; o[4] = m ? v_wall : -1.0f; o[5] = m ? c_fd[u] : -1.0f;
                     if (LAYOUT == LAYOUT_DEFAULT_ROCKS) o[6] = m ? v_rock : -1.0f;
@@ -626,6 +642,22 @@ k_act(const KP p, const int8_t *__restrict__ rotation, const int8_t *__restrict_
                 // copy the row out: two 16-byte stores per lane over the fully-inside float4s of the
                 // aligned window [mis, mis+row), one 4-byte store for the <= 6 edge floats; lanes
                 // with nothing left repeat a valid store (same address, same data)
+                if (OBS16) {
+                    // one 16-byte store per lane over the whole 8-element groups of the aligned window
+                    // [mis16, mis16 + row) (<= 60 groups), one 2-byte store for the <= 14 edge elements
+                    uint16_t *st16 = reinterpret_cast<uint16_t *>(stage), *d_al = dst16 - mis16;
+                    const uint32_t g_lo = (mis16 + 7) >> 3, g_hi = (mis16 + row) >> 3;
+                    const uint32_t ga = min(g_lo + (uint32_t)lane, g_hi - 1);
+                    const uint4 wa = reinterpret_cast<const uint4 *>(st16)[ga];
+                    const uint32_t hd16 = 8 * g_lo - mis16, tl16 = mis16 + row - 8 * g_hi;
+                    const uint32_t fe16 = (uint32_t)lane < hd16 ? mis16 + lane
+                                          : ((uint32_t)lane - hd16 < tl16 ? 8 * g_hi + ((uint32_t)lane - hd16) : mis16);
+                    const uint16_t we = st16[fe16];
+                    store_stream(reinterpret_cast<uint4 *>(d_al) + ga, wa);
+                    store_stream(d_al + fe16, we);
+                    wave_lds_sync();
+                    continue;
+                }
                 float *dst_al = dst - mis;
                 const uint32_t j_lo = (mis + 3) >> 2, j_hi = (mis + row) >> 2; // interior float4s [j_lo, j_hi)
                 const uint32_t ja = min(j_lo + (uint32_t)lane, j_hi - 1), jb = min(j_lo + 64u + (uint32_t)lane, j_hi - 1);
@@ -1945,32 +1977,32 @@ static int act_layout(const KP &p)
     return p.K == 6 ? LAYOUT_DEFAULT : LAYOUT_DEFAULT_ROCKS;
 }
 
-template <int C, bool ST, int LAYOUT, bool FAST, int TPB>
+template <int C, bool ST, int LAYOUT, bool FAST, int TPB, bool OBS16 = false>
 static hipError_t launch_act_t(const KP &p, const ActPlan &pl, const int8_t *rot, const int8_t *ph, int cur,
                                float *obs, float *agent_state, float *reward, uint8_t *done, int flags,
                                const double *jitter, int out_buf, hipStream_t st)
 {
     static size_t attr_lds = 0; // dynamic-LDS opt-in is per kernel function, set once per size
     if (pl.lds > attr_lds) {
-        hipError_t err = hipFuncSetAttribute((const void *)k_act<C, ST, LAYOUT, FAST, TPB>,
+        hipError_t err = hipFuncSetAttribute((const void *)k_act<C, ST, LAYOUT, FAST, TPB, OBS16>,
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds);
         if (err != hipSuccess) return err;
         attr_lds = pl.lds;
     }
-    hipLaunchKernelGGL((k_act<C, ST, LAYOUT, FAST, TPB>), dim3(p.E), dim3(TPB), pl.lds, st, p, rot, ph, cur, obs,
+    hipLaunchKernelGGL((k_act<C, ST, LAYOUT, FAST, TPB, OBS16>), dim3(p.E), dim3(TPB), pl.lds, st, p, rot, ph, cur, obs,
                        agent_state, reward, done, flags, jitter, out_buf);
     return hipGetLastError();
 }
 
-template <int C, bool ST, int LAYOUT, bool FAST>
+template <int C, bool ST, int LAYOUT, bool FAST, bool OBS16 = false>
 static hipError_t launch_act_k(const KP &p, const ActPlan &pl, const int8_t *rot, const int8_t *ph, int cur,
                                float *obs, float *agent_state, float *reward, uint8_t *done, int flags,
                                const double *jitter, int out_buf, hipStream_t st)
 {
     if (pl.threads == 1024)
-        return launch_act_t<C, ST, LAYOUT, FAST, 1024>(p, pl, rot, ph, cur, obs, agent_state, reward, done, flags,
+        return launch_act_t<C, ST, LAYOUT, FAST, 1024, OBS16>(p, pl, rot, ph, cur, obs, agent_state, reward, done, flags,
                                                        jitter, out_buf, st);
-    return launch_act_t<C, ST, LAYOUT, FAST, 512>(p, pl, rot, ph, cur, obs, agent_state, reward, done, flags, jitter,
+    return launch_act_t<C, ST, LAYOUT, FAST, 512, OBS16>(p, pl, rot, ph, cur, obs, agent_state, reward, done, flags, jitter,
                                                   out_buf, st);
 }
 
@@ -1988,6 +2020,15 @@ static hipError_t launch_act_c(const KP &p, const int8_t *rot, const int8_t *ph,
                       !(flags & 0x700); // (ACT_ABL_NO_EXPLORE is honoured by the pipelined loop too)
 #define ACT_GO(ST, LY, FA) \
     return launch_act_k<C, ST, LY, FA>(p, pl, rot, ph, cur, obs, agent_state, reward, done, flags, jitter, out_buf, st)
+#define ACT_GO16(ST, LY) \
+    return launch_act_k<C, ST, LY, true, true>(p, pl, rot, ph, cur, obs, agent_state, reward, done, flags, jitter, out_buf, st)
+    if (flags & ACT_OBS_BF16) { // bfloat16 observations: the pipelined loop on a default channel layout
+        if (!fast || C != 2) return hipErrorNotSupported;
+        if constexpr (C == 2) {
+            if (layout == LAYOUT_DEFAULT) { if (pl.static_lds) ACT_GO16(true, LAYOUT_DEFAULT); else ACT_GO16(false, LAYOUT_DEFAULT); }
+            else { if (pl.static_lds) ACT_GO16(true, LAYOUT_DEFAULT_ROCKS); else ACT_GO16(false, LAYOUT_DEFAULT_ROCKS); }
+        }
+    }
     if (C == 2 && layout != LAYOUT_GENERIC) {
         constexpr int LD = C == 2 ? LAYOUT_DEFAULT : LAYOUT_GENERIC, LR = C == 2 ? LAYOUT_DEFAULT_ROCKS : LAYOUT_GENERIC;
         constexpr bool F = C == 2;
@@ -2002,6 +2043,7 @@ static hipError_t launch_act_c(const KP &p, const int8_t *rot, const int8_t *ph,
     if (pl.static_lds) ACT_GO(true, LAYOUT_GENERIC, false);
     ACT_GO(false, LAYOUT_GENERIC, false);
 #undef ACT_GO
+#undef ACT_GO16
 }
 
 hipError_t antsrl_launch_act(const KP &p, const int8_t *rot, const int8_t *ph, int cur, float *obs,

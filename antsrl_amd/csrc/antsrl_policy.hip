@@ -23,6 +23,7 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 #define POL_MAX_KSTEPS 64 // (F + 2) <= 1024 inputs: W1 as bf16 fits 64 KiB of LDS
 
 struct __attribute__((packed, aligned(4))) F4 { float v[4]; }; // 4-byte aligned 16-byte load
+struct __attribute__((packed, aligned(4))) D3 { uint32_t v[3]; }; // 4-byte aligned 12-byte load
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 #define POL_KC 64                 // inputs per staged chunk (4 MFMA k-steps)
 #define POL_SROW (POL_KC + 8)     // bf16 per staged row: 144-byte stride = 16-byte aligned rows, 4-bank skew per row
@@ -34,6 +35,7 @@ __device__ __forceinline__ void pol_wave_sync()
     __builtin_amdgcn_wave_barrier();
 }
 
+template <bool OBS16> // OBS16: `obs` points to bfloat16 rows (antsrl_set_obs_format), same shape
 __global__ void __launch_bounds__(256)
 k_policy_mlp(const float *__restrict__ obs, const float *__restrict__ agent_state, const float *__restrict__ w1,
              const float *__restrict__ b1, const float *__restrict__ w2, const float *__restrict__ b2,
@@ -90,6 +92,7 @@ k_policy_mlp(const float *__restrict__ obs, const float *__restrict__ agent_stat
         const int ant = min(t * 32 + r, M - 1); // clamped: duplicates are not written back
         const int rows = min(32, M - t * 32);
         const float *tile = obs + (size_t)t * 32 * F;
+        const uint16_t *tile16 = reinterpret_cast<const uint16_t *>(obs) + (size_t)t * 32 * F;
         const __bf16 *wrow = w1s + r * KP + 8 * h;
         f32x16 acc;
 #pragma unroll
@@ -97,11 +100,24 @@ k_policy_mlp(const float *__restrict__ obs, const float *__restrict__ agent_stat
 #define POL_LOAD(V, CH)                                                                                  \
     {                                                                                                    \
         const int k_ = POL_KC * (CH) + 4 * lf;                                                           \
-        if (POL_KC * ((CH) + 1) <= F) { /* every input of the chunk lies inside the observation rows */  \
+        if (POL_KC * ((CH) + 1) + (OBS16 ? 2 : 0) <= F) { /* every input of the chunk (and the bf16 loader's */ \
+            /* 4 bytes of read-ahead) lies inside the observation rows                                   */ \
             _Pragma("unroll") for (int i = 0; i < 8; ++i)                                                \
             {                                                                                            \
                 const int a = min(la + 4 * i, rows - 1);                                                 \
-                V[i] = *reinterpret_cast<const F4 *>(tile + (size_t)a * F + k_);                         \
+                if (OBS16) {                                                                             \
+                    /* 4 bf16 at a 2-byte aligned position: three ALIGNED dwords of the tile (its base is */ \
+                    /* 64-byte aligned) and a funnel shift, instead of four 2-byte loads                 */ \
+                    const uint32_t ei = (uint32_t)a * (uint32_t)F + (uint32_t)k_, sh = (ei & 1u) * 16u;  \
+                    const D3 d = *reinterpret_cast<const D3 *>(reinterpret_cast<const uint32_t *>(tile16) + (ei >> 1)); \
+                    const uint32_t x0 = __builtin_amdgcn_alignbit(d.v[1], d.v[0], sh);                   \
+                    const uint32_t x1 = __builtin_amdgcn_alignbit(d.v[2], d.v[1], sh);                   \
+                    V[i].v[0] = __builtin_bit_cast(float, x0 << 16);                                     \
+                    V[i].v[1] = __builtin_bit_cast(float, x0 & 0xFFFF0000u);                             \
+                    V[i].v[2] = __builtin_bit_cast(float, x1 << 16);                                     \
+                    V[i].v[3] = __builtin_bit_cast(float, x1 & 0xFFFF0000u);                             \
+                } else                                                                                   \
+                    V[i] = *reinterpret_cast<const F4 *>(tile + (size_t)a * F + k_);                     \
             }                                                                                            \
         } else if ((CH) < nchunks) { /* end of the row, the two agent_state inputs, zero pad */          \
             _Pragma("unroll") for (int i = 0; i < 8; ++i)                                                \
@@ -110,7 +126,8 @@ k_policy_mlp(const float *__restrict__ obs, const float *__restrict__ agent_stat
                 _Pragma("unroll") for (int j = 0; j < 4; ++j)                                            \
                 {                                                                                        \
                     const int kk = k_ + j;                                                               \
-                    V[i].v[j] = kk < F ? tile[(size_t)a * F + kk]                                        \
+                    V[i].v[j] = kk < F ? (OBS16 ? __builtin_bit_cast(float, (uint32_t)tile16[(size_t)a * F + kk] << 16) \
+                                                : tile[(size_t)a * F + kk])                              \
                                        : (kk < IN ? agent_state[((size_t)t * 32 + a) * 2 + (kk - F)] : 0.0f); \
                 }                                                                                        \
             }                                                                                            \
@@ -174,7 +191,7 @@ k_policy_mlp(const float *__restrict__ obs, const float *__restrict__ agent_stat
 
 hipError_t antsrl_launch_policy(const float *obs, const float *agent_state, const float *w1, const float *b1,
                                 const float *w2, const float *b2, const float *w3, const float *b3, int8_t *rot,
-                                int8_t *ph, float *logits, int M, int F, hipStream_t st)
+                                int8_t *ph, float *logits, int M, int F, hipStream_t st, bool obs_bf16)
 {
     const int ksteps = (F + 2 + 15) / 16;
     if (ksteps > POL_MAX_KSTEPS || M < 1 || F < 1) return hipErrorInvalidValue;
@@ -182,7 +199,11 @@ hipError_t antsrl_launch_policy(const float *obs, const float *agent_state, cons
     int blocks = (ntiles + 3) / 4;
     if (blocks > 256 * 3) blocks = 256 * 3; // tiles are looped; 3 workgroups (41 KiB of LDS each) per CU, one round
     const size_t lds = (size_t)POL_HIDDEN * (16 * ksteps + 8) * 2 + 4 * 32 * (size_t)POL_SROW * 2; // W1 + 4 wave tiles
-    hipLaunchKernelGGL(k_policy_mlp, dim3(blocks), dim3(256), lds, st, obs, agent_state, w1, b1, w2, b2, w3, b3, rot,
-                       ph, logits, M, F, ksteps);
+    if (obs_bf16)
+        hipLaunchKernelGGL(k_policy_mlp<true>, dim3(blocks), dim3(256), lds, st, obs, agent_state, w1, b1, w2, b2, w3, b3,
+                           rot, ph, logits, M, F, ksteps);
+    else
+        hipLaunchKernelGGL(k_policy_mlp<false>, dim3(blocks), dim3(256), lds, st, obs, agent_state, w1, b1, w2, b2, w3, b3,
+                           rot, ph, logits, M, F, ksteps);
     return hipGetLastError();
 }

@@ -51,14 +51,20 @@ class LinearPolicy:
                 setattr(self, "w" + attr, w)
                 setattr(self, "b" + attr, b)
 
-    def act(self, obs: torch.Tensor, agent_state: torch.Tensor, logits: Optional[torch.Tensor] = None):
-        """obs float32 [..., P, P, K] and agent_state float32 [..., 2] on the GPU ->
-        (rotation int8 [...], pheromone int8 [...] or None), ready to pass to step()."""
+    def act(self, obs: torch.Tensor, agent_state: torch.Tensor, logits: Optional[torch.Tensor] = None, env=None):
+        """obs [..., P, P, K] (float32, or bfloat16 from a BatchedAntsEnv(obs_dtype=torch.bfloat16) passed as
+        `env`) and agent_state float32 [..., 2] on the GPU -> (rotation int8 [...], pheromone int8 [...] or
+        None), ready to pass to step()."""
         lead = obs.shape[:-3]
         m = 1
         for d in lead:
             m *= d
-        assert obs.is_contiguous() and agent_state.is_contiguous() and obs.dtype == torch.float32
+        assert obs.is_contiguous() and agent_state.is_contiguous()
+        if obs.dtype == torch.bfloat16:
+            assert env is not None and env.obs.dtype == torch.bfloat16, "bfloat16 observations: pass the env that produced them"
+        else:
+            assert obs.dtype == torch.float32 and (env is None or env.obs.dtype == torch.float32)
+        handle = env._h if (env is not None and obs.dtype == torch.bfloat16) else None
         assert obs.numel() == m * self.n_features and agent_state.numel() == m * 2
         if self._rot is None or self._rot.numel() != m:
             self._rot = torch.empty((m,), dtype=torch.int8, device=self.device)
@@ -69,7 +75,7 @@ class LinearPolicy:
 
         with torch.cuda.device(self.device):
             st = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
-            _lib.check(self._lib.antsrl_policy_mlp(None, p(obs), p(agent_state), m, self.n_features, p(self.w1),
+            _lib.check(self._lib.antsrl_policy_mlp(handle, p(obs), p(agent_state), m, self.n_features, p(self.w1),
                                                    p(self.b1), p(self.w2), p(self.b2), p(self.w3), p(self.b3),
                                                    p(self._rot), p(self._ph), p(logits), st), "policy_mlp")
         rot = self._rot.view(lead)

@@ -41,10 +41,10 @@ CONFIGS = {
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 
-def algorithmic_bytes(N, W, H, Cn, K, P=49):
+def algorithmic_bytes(N, W, H, Cn, K, P=49, obs_bytes=4):
     """SURVEY.md §8(d) per env-step figure, split by the kernel that moves each term."""
     sweep = 2 * Cn * W * H * 4 + W * H                 # pheromone read+write sweep, wall mask
-    act = N * P * K * 4 + N * 60 + N * 12 + N * 8      # obs write, ant state r+w, agent_state+reward, food RMW
+    act = N * P * K * obs_bytes + N * 60 + N * 12 + N * 8  # obs write, ant state r+w, agent_state+reward, food RMW
     update = N * Cn * 8                                # deposit RMW
     return dict(sweep=sweep, act=act, update=update, total=sweep + act + update)
 
@@ -128,6 +128,8 @@ def main():
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--policy", default=None, choices=["random", "mlp"],
                     help="mlp: the reference's linear DQN net evaluated in-loop on the GPU (bf16 MFMA)")
+    ap.add_argument("--obs-dtype", default=None, choices=["f32", "bf16"],
+                    help="observation tensor format (default: f32; c5, whose bf16 policy rounds its input anyway: bf16)")
     ap.add_argument("--explicit-sweep", action="store_true",
                     help="force the per-step pheromone sweep kernel (default: scaled units, no sweep)")
     args = ap.parse_args()
@@ -164,7 +166,9 @@ def main():
         g = np.exp(-(ax[:, None] ** 2 + ax[None, :] ** 2) / 4.5)
         extra["filt"] = g / g.sum() * (1 - 0.001)
     cfg = cm.make_cfg(E, W_["N"], W_["W"], W_["H"], **extra)
-    env = BatchedAntsEnv(cfg, dev)
+    policy_kind = args.policy or W_.get("policy", "random")
+    obs_dtype = args.obs_dtype or ("bf16" if policy_kind == "mlp" else "f32")
+    env = BatchedAntsEnv(cfg, dev, obs_dtype=torch.bfloat16 if obs_dtype == "bf16" else torch.float32)
     env.reset(synth_init(cfg, seed=1234, env_offset=rank * E))
     RING = 8
     g = torch.Generator(device=dev)
@@ -176,7 +180,6 @@ def main():
         from antsrl_amd.dist import RewardGather
         gather = RewardGather(world * E, cfg.n_ants, dev)
 
-    policy_kind = args.policy or W_.get("policy", "random")
     policy = None
     if policy_kind == "mlp":
         from antsrl_amd.policy import LinearPolicy
@@ -185,7 +188,7 @@ def main():
 
     def one_step(t):
         if policy is not None:  # agent.get_action on the device, then api.step + env.update
-            a_rot, a_ph = policy.act(env.obs, env.agent_state)
+            a_rot, a_ph = policy.act(env.obs, env.agent_state, env=env)
             env.step_update(a_rot, a_ph, None)
         else:
             env.step_update(rot[t % RING], ph[t % RING], None)
@@ -228,7 +231,7 @@ def main():
 
     out = None
     if rank == 0:
-        ab = algorithmic_bytes(cfg.n_ants, cfg.w, cfg.h, cfg.n_phero, cfg.n_channels)
+        ab = algorithmic_bytes(cfg.n_ants, cfg.w, cfg.h, cfg.n_phero, cfg.n_channels, obs_bytes=2 if obs_dtype == "bf16" else 4)
         kern = {}
         if timing:
             ms = np.array([[evs.elapsed_ms(4 * j + i, 4 * j + i + 1) for i in range(3)] for j in range(len(timed_steps))])
@@ -258,7 +261,7 @@ def main():
             "vs_baseline": None, "dtype": "f64 ant kinematics / f32 grids", "data": "synthetic",
             "config": {"workload": W_["desc"], "envs_per_gpu": E, "ants": cfg.n_ants, "grid": [cfg.w, cfg.h],
                        "pheromone_channels": cfg.n_phero, "rocks": cfg.n_rocks, "obs_channels": cfg.n_channels,
-                       "filter_radius": cfg.filter_radius, "reward": "ExplorationReward",
+                       "filter_radius": cfg.filter_radius, "reward": "ExplorationReward", "obs_dtype": obs_dtype,
                        "pheromone_update": "scaled units (no per-step sweep)" if cm.uses_scaled_units(cfg)
                        else "explicit sweep kernel",
                        "policy": ("linear DQN net (F+2 -> 32 -> 3+3) in-loop, bf16 MFMA" if policy is not None

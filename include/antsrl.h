@@ -249,6 +249,18 @@ int antsrl_step_update(AntsHandle *h, const int8_t *rotation, const int8_t *pher
  * clears itself. */
 int antsrl_set_timing_events(AntsHandle *h, void *const *events);
 
+/* Observation tensor format (no reference counterpart: the reference's perception is float64 numpy,
+ * cast to float32 by torch.Tensor(state) in the agents, collect_agent_memory.py:194).
+ * ANTSRL_OBS_F32 (default): `obs` arguments are float [E][N][P][P][K].
+ * ANTSRL_OBS_BF16: `obs` arguments point to bfloat16 (uint16_t) buffers of the same shape holding the
+ * same values rounded to nearest even — half the bytes written per step, and what the bf16 policy
+ * (antsrl_policy_mlp*) rounds its input to anyway.  Supported for 2 pheromone channels, the
+ * generator's channel order and perceptions of at most 64 cells; otherwise the step returns
+ * ANTSRL_E_UNSUPPORTED. */
+#define ANTSRL_OBS_F32 0
+#define ANTSRL_OBS_BF16 1
+int antsrl_set_obs_format(AntsHandle *h, int format);
+
 /* Profiling read-out (no reference counterpart).  With ANTSRL_ABLATE=32768 in the environment the
  * act kernel stamps a per-workgroup phase timeline; this copies the first n_wg records (8 x u64 each:
  * 100 MHz timestamps at entry / perception start / perception end / exit, then HW_ID and XCC_ID) to
@@ -269,7 +281,8 @@ int antsrl_set_activation(AntsHandle *h, const float *act, double new_deposit_st
  *     pheromone = argmax(layer3(out))      (skipped if w3 NULL)   layer3: w3 float [3][32],  b3 [3]
  * Weights are PyTorch nn.Linear layouts, device pointers.  M = number of ants (E*N), F = P*P*K.
  * rotation/pheromone: int8 [M], directly usable as antsrl_step's actions.  logits (float [M][6],
- * nullable) receives the six head outputs.  Stateless: `h` only supplies nothing but error context. */
+ * nullable) receives the six head outputs.  `h` may be NULL; a handle set to ANTSRL_OBS_BF16
+ * (antsrl_set_obs_format) makes `obs` a bfloat16 buffer of the same shape. */
 int antsrl_policy_mlp(AntsHandle *h, const float *obs, const float *agent_state, int64_t n_ants, int32_t n_features,
                       const float *w1, const float *b1, const float *w2, const float *b2, const float *w3,
                       const float *b3, int8_t *rotation, int8_t *pheromone, float *logits, void *stream);

@@ -421,3 +421,33 @@ def test_known_answers(torch_mod):
     mask = cm.mask_array(cfg)
     assert (o[:, ~mask, :] == -1).all()
     assert set(np.unique(o[:, mask, 0])) <= {0.0, 1.0}
+
+
+def test_bfloat16_observation_format(torch_mod):
+    """antsrl_set_obs_format(BF16): the observation tensor holds exactly the float32 observation rounded
+    to nearest even, for both default layouts (with and without rocks), odd row alignments and an odd
+    ant count; unsupported layouts are refused, state and rewards do not depend on the format."""
+    from antsrl_amd import _lib, config as cm
+    from antsrl_amd.batched import BatchedAntsEnv
+    from antsrl_amd.synth import random_actions, synth_init
+    torch = torch_mod
+    for (E, N, W, H, R) in [(3, 129, 64, 48, 0), (2, 512, 256, 256, 8), (2, 77, 40, 40, 3)]:
+        cfg = cm.make_cfg(E, N, W, H, n_rocks=R, deposit_strength=256.0)
+        init = synth_init(cfg, seed=31, n_food_discs=5, food_rmin=2, food_rmax=5)
+        a, b = BatchedAntsEnv(cfg), BatchedAntsEnv(cfg, obs_dtype=torch.bfloat16)
+        a.reset(init)
+        b.reset(init)
+        rot, ph = random_actions(cfg, 6, seed=3)
+        oa, ob = a.observe()[0], b.observe()[0]
+        assert ob.dtype == torch.bfloat16 and torch.equal(oa.to(torch.bfloat16), ob)
+        for t in range(6):
+            ra = a.step_update(rot[t], ph[t], None)
+            rb = b.step_update(rot[t], ph[t], None)
+            assert torch.equal(ra[0].to(torch.bfloat16), rb[0]), "step %d" % t
+            assert all(torch.equal(x, y) for x, y in zip(ra[1:], rb[1:]))
+        assert torch.equal(a.read_state(cm.S_ANTS_XYT), b.read_state(cm.S_ANTS_XYT))
+    cfg = cm.make_cfg(1, 20, 32, 32, channels=[(cm.CH_FOOD, 0), (cm.CH_ANTS, 0)])
+    env = BatchedAntsEnv(cfg, obs_dtype=torch.bfloat16)
+    env.reset(synth_init(cfg, seed=1, n_food_discs=2, food_rmin=2, food_rmax=3))
+    with pytest.raises(_lib.AntsrlError, match="bfloat16 observations need"):
+        env.observe()

@@ -50,3 +50,30 @@ def test_policy_rotation_only_head():
     top2 = ref.topk(2, dim=1).values
     clear = (top2[:, 0] - top2[:, 1]) > 4e-3
     assert torch.equal((rot + 1)[clear].long(), ref.argmax(dim=1)[clear])
+
+
+def test_policy_on_bfloat16_observations_matches_float32_path():
+    """A bf16 observation tensor (antsrl_set_obs_format) is what the policy rounds its float32 input
+    to: actions and logits are identical on both paths."""
+    import torch
+    from antsrl_amd import config as cm
+    from antsrl_amd.batched import BatchedAntsEnv
+    from antsrl_amd.policy import LinearPolicy
+    from antsrl_amd.synth import random_actions, synth_init
+    for R in (0, 3):
+        cfg = cm.make_cfg(3, 200, 64, 64, n_rocks=R, deposit_strength=256.0)
+        init = synth_init(cfg, seed=8, n_food_discs=5, food_rmin=2, food_rmax=5)
+        a, b = BatchedAntsEnv(cfg), BatchedAntsEnv(cfg, obs_dtype=torch.bfloat16)
+        a.reset(init)
+        b.reset(init)
+        rot, ph = random_actions(cfg, 3, seed=2)
+        for t in range(3):
+            a.step_update(rot[t], ph[t], None)
+            b.step_update(rot[t], ph[t], None)
+        pol = LinearPolicy(cfg.pside * cfg.pside * cfg.n_channels, a.device, seed=4)
+        la = torch.empty((3 * 200, 6), device=a.device)
+        lb = torch.empty_like(la)
+        ra, pa = pol.act(a.obs, a.agent_state, logits=la)
+        ra, pa = ra.clone(), pa.clone()
+        rb, pb = pol.act(b.obs, b.agent_state, logits=lb, env=b)
+        assert torch.equal(la, lb) and torch.equal(ra, rb) and torch.equal(pa, pb)
