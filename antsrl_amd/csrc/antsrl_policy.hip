@@ -197,8 +197,10 @@ hipError_t antsrl_launch_policy(const float *obs, const float *agent_state, cons
     if (ksteps > POL_MAX_KSTEPS || M < 1 || F < 1) return hipErrorInvalidValue;
     const int ntiles = (M + 31) / 32;
     int blocks = (ntiles + 3) / 4;
-    if (blocks > 256 * 3) blocks = 256 * 3; // tiles are looped; 3 workgroups (41 KiB of LDS each) per CU, one round
     const size_t lds = (size_t)POL_HIDDEN * (16 * ksteps + 8) * 2 + 4 * 32 * (size_t)POL_SROW * 2; // W1 + 4 wave tiles
+    int per_cu = (int)((160 * 1024) / lds); // resident workgroups per CU by LDS (38-41 KiB each for the reference's sizes)
+    per_cu = per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu);
+    if (blocks > 256 * per_cu) blocks = 256 * per_cu; // tiles are looped: one round of workgroups
     if (obs_bf16)
         hipLaunchKernelGGL(k_policy_mlp<true>, dim3(blocks), dim3(256), lds, st, obs, agent_state, w1, b1, w2, b2, w3, b3,
                            rot, ph, logits, M, F, ksteps);
