@@ -49,9 +49,18 @@ k_policy_mlp(const float *__restrict__ obs, const float *__restrict__ agent_stat
     const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
     const int IN = F + 2;
-    for (int row = threadIdx.x >> 6; row < POL_HIDDEN; row += blockDim.x >> 6) // a wave per row: no divisions
-        for (int k = lane; k < 16 * ksteps; k += 64)
-            w1s[row * KP + k] = (__bf16)(k < IN ? w1[(size_t)row * IN + k] : 0.0f);
+    // W1 -> bf16 in LDS: a wave takes 8 of the 32 rows; for each 64-column slice its 8 loads are issued
+    // together (one round trip per slice, not one per element)
+    for (int k = lane; k < 16 * ksteps; k += 64) {
+        float wv[POL_HIDDEN / 4];
+#pragma unroll
+        for (int j = 0; j < POL_HIDDEN / 4; ++j) {
+            const int row = (int)(threadIdx.x >> 6) + 4 * j;
+            wv[j] = k < IN ? w1[(size_t)row * IN + k] : 0.0f;
+        }
+#pragma unroll
+        for (int j = 0; j < POL_HIDDEN / 4; ++j) w1s[((int)(threadIdx.x >> 6) + 4 * j) * KP + k] = (__bf16)wv[j];
+    }
     // Heads as a second MFMA: logits^T [32 (6 used) x 32 ants] = W23 [32 x 32 hidden] . H^T, with the
     // first accumulator reused AS the B operand: its registers 8s..8s+7 (converted to bf16) are the
     // fragment of k-step s, in the permuted k order  k(j, h) = 16 s + 8 (j >> 2) + 4 h + (j & 3)
@@ -100,23 +109,10 @@ k_policy_mlp(const float *__restrict__ obs, const float *__restrict__ agent_stat
 #define POL_LOAD(V, CH)                                                                                  \
     {                                                                                                    \
         const int k_ = POL_KC * (CH) + 4 * lf;                                                           \
-        if (POL_KC * ((CH) + 1) + (OBS16 ? 2 : 0) <= F) { /* every input of the chunk (and the bf16 loader's */ \
-            /* 4 bytes of read-ahead) lies inside the observation rows                                   */ \
+        if (POL_KC * ((CH) + 1) <= F) { /* every input of the chunk lies inside the observation rows */  \
             _Pragma("unroll") for (int i = 0; i < 8; ++i)                                                \
             {                                                                                            \
                 const int a = min(la + 4 * i, rows - 1);                                                 \
-                if (OBS16) {                                                                             \
-                    /* 4 bf16 at a 2-byte aligned position: three ALIGNED dwords of the tile (its base is */ \
-                    /* 64-byte aligned) and a funnel shift, instead of four 2-byte loads                 */ \
-                    const uint32_t ei = (uint32_t)a * (uint32_t)F + (uint32_t)k_, sh = (ei & 1u) * 16u;  \
-                    const D3 d = *reinterpret_cast<const D3 *>(reinterpret_cast<const uint32_t *>(tile16) + (ei >> 1)); \
-                    const uint32_t x0 = __builtin_amdgcn_alignbit(d.v[1], d.v[0], sh);                   \
-                    const uint32_t x1 = __builtin_amdgcn_alignbit(d.v[2], d.v[1], sh);                   \
-                    V[i].v[0] = __builtin_bit_cast(float, x0 << 16);                                     \
-                    V[i].v[1] = __builtin_bit_cast(float, x0 & 0xFFFF0000u);                             \
-                    V[i].v[2] = __builtin_bit_cast(float, x1 << 16);                                     \
-                    V[i].v[3] = __builtin_bit_cast(float, x1 & 0xFFFF0000u);                             \
-                } else                                                                                   \
                     V[i] = *reinterpret_cast<const F4 *>(tile + (size_t)a * F + k_);                     \
             }                                                                                            \
         } else if ((CH) < nchunks) { /* end of the row, the two agent_state inputs, zero pad */          \
@@ -126,13 +122,67 @@ k_policy_mlp(const float *__restrict__ obs, const float *__restrict__ agent_stat
                 _Pragma("unroll") for (int j = 0; j < 4; ++j)                                            \
                 {                                                                                        \
                     const int kk = k_ + j;                                                               \
-                    V[i].v[j] = kk < F ? (OBS16 ? __builtin_bit_cast(float, (uint32_t)tile16[(size_t)a * F + kk] << 16) \
-                                                : tile[(size_t)a * F + kk])                              \
+                    V[i].v[j] = kk < F ? tile[(size_t)a * F + kk]                                        \
                                        : (kk < IN ? agent_state[((size_t)t * 32 + a) * 2 + (kk - F)] : 0.0f); \
                 }                                                                                        \
             }                                                                                            \
         }                                                                                                \
     }
+        // bfloat16 rows: 4 elements per lane and ant stay PACKED in two registers from the load to the LDS
+        // tile (three ALIGNED dwords of the tile — its base is 64-byte aligned — and a funnel shift stand in
+        // for a 2-byte aligned 8-byte load), which leaves room for two chunks in flight.
+#define POL_LOAD16(V, CH)                                                                                \
+    {                                                                                                    \
+        const int k_ = POL_KC * (CH) + 4 * lf;                                                           \
+        if (POL_KC * ((CH) + 1) + 2 <= F) { /* chunk + the loader's 4 bytes of read-ahead inside the rows */ \
+            _Pragma("unroll") for (int i = 0; i < 8; ++i)                                                \
+            {                                                                                            \
+                const uint32_t ei = (uint32_t)min(la + 4 * i, rows - 1) * (uint32_t)F + (uint32_t)k_;    \
+                const uint32_t sh = (ei & 1u) * 16u;                                                     \
+                const D3 d = *reinterpret_cast<const D3 *>(reinterpret_cast<const uint32_t *>(tile16) + (ei >> 1)); \
+                V[i].x = __builtin_amdgcn_alignbit(d.v[1], d.v[0], sh);                                  \
+                V[i].y = __builtin_amdgcn_alignbit(d.v[2], d.v[1], sh);                                  \
+            }                                                                                            \
+        } else if ((CH) < nchunks) { /* end of the row, the two agent_state inputs, zero pad */          \
+            _Pragma("unroll") for (int i = 0; i < 8; ++i)                                                \
+            {                                                                                            \
+                const int a = min(la + 4 * i, rows - 1);                                                 \
+                uint32_t e_[4];                                                                          \
+                _Pragma("unroll") for (int j = 0; j < 4; ++j)                                            \
+                {                                                                                        \
+                    const int kk = k_ + j;                                                               \
+                    e_[j] = kk < F ? (uint32_t)tile16[(size_t)a * F + kk]                                \
+                                   : (kk < IN ? (uint32_t)__builtin_bit_cast(uint16_t, (__bf16)agent_state[((size_t)t * 32 + a) * 2 + (kk - F)]) : 0u); \
+                }                                                                                        \
+                V[i].x = e_[0] | (e_[1] << 16);                                                          \
+                V[i].y = e_[2] | (e_[3] << 16);                                                          \
+            }                                                                                            \
+        }                                                                                                \
+    }
+        if constexpr (OBS16) {
+            uint2 q0[8], q1[8], q2[8];
+            POL_LOAD16(q0, 0)
+            POL_LOAD16(q1, 1)
+            for (int c = 0; c < nchunks; ++c) {
+                POL_LOAD16(q2, c + 2)
+                pol_wave_sync(); // the previous chunk's fragment reads are done
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    *reinterpret_cast<uint2 *>(stg + (la + 4 * i) * POL_SROW + 4 * lf) = q0[i];
+                pol_wave_sync();
+                const int s_end = min(ksteps - (POL_KC / 16) * c, POL_KC / 16);
+                for (int s = 0; s < s_end; ++s) {
+                    const bf16x8 bfrag = *reinterpret_cast<const bf16x8 *>(stg + r * POL_SROW + 16 * s + 8 * h);
+                    const bf16x8 afrag = *reinterpret_cast<const bf16x8 *>(wrow + 16 * ((POL_KC / 16) * c + s));
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag, acc, 0, 0, 0);
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    q0[i] = q1[i];
+                    q1[i] = q2[i];
+                }
+            }
+        } else {
         F4 v[8], nx[8];
         POL_LOAD(v, 0)
         for (int c = 0; c < nchunks; ++c) {
@@ -155,7 +205,9 @@ k_policy_mlp(const float *__restrict__ obs, const float *__restrict__ agent_stat
 #pragma unroll
             for (int i = 0; i < 8; ++i) v[i] = nx[i];
         }
+        }
 #undef POL_LOAD
+#undef POL_LOAD16
         // acc[g] = hidden[(g&3) + 8*(g>>2) + 4*h] of ant r (before bias)
         f32x16 acc2;
 #pragma unroll
