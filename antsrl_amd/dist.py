@@ -71,6 +71,52 @@ class RewardGather:
         full = self._recv if self.equal else self._recv[self._keep]
         return full[:, : self.N], full[:, self.N].to(torch.uint8)
 
+    # ------------------------------------------------------------------ zero-copy form
+    # The step kernels can write reward / done straight into the gather's send buffer: two byte buffers
+    # [E_local*N*4 reward | E_local done] used alternately (the gather of step t reads slot t % 2 while
+    # step t + 1 writes the other one), so no staging copy is enqueued at all.
+    def outputs(self, slot: int):
+        """(reward float32 [E_local, N], done uint8 [E_local]) views of send slot `slot` (0 or 1): bind them
+        as the env's output tensors for the step whose results start_slot(slot) will gather."""
+        if not hasattr(self, "_zc"):
+            lo, hi = self.ranges[self.rank]
+            n_loc = hi - lo
+            nb = self.max_local * self.N * 4 + self.max_local
+            dev = self._send.device
+            self._zc = dict(n_loc=n_loc, nb=nb,
+                            send=[torch.zeros(nb, dtype=torch.uint8, device=dev) for _ in range(2)],
+                            recv=[torch.empty(self.world * nb, dtype=torch.uint8, device=dev) for _ in range(2)],
+                            work=[None, None])
+        z = self._zc
+        if z["work"][slot] is not None:
+            z["work"][slot].wait()  # the gather that last read this slot is ordered before the kernels that rewrite it
+        sb = z["send"][slot]
+        rew = sb[: self.max_local * self.N * 4].view(torch.float32).view(self.max_local, self.N)[: z["n_loc"]]
+        done = sb[self.max_local * self.N * 4:][: z["n_loc"]]
+        return rew, done
+
+    def start_slot(self, slot: int) -> None:
+        """All-gather send slot `slot` (written by the step just enqueued) without blocking the stream."""
+        z = self._zc
+        if z["work"][slot] is not None:
+            z["work"][slot].wait()
+        z["work"][slot] = dist.all_gather_into_tensor(z["recv"][slot], z["send"][slot], group=self.group, async_op=True)
+
+    def finish_slot(self, slot: int):
+        """-> (reward [E_total, N], done [E_total] uint8) of the gather started on `slot`, or None."""
+        z = getattr(self, "_zc", None)
+        if z is None or z["work"][slot] is None:
+            return None
+        z["work"][slot].wait()
+        z["work"][slot] = None
+        rb = z["recv"][slot].view(self.world, z["nb"])
+        rew = rb[:, : self.max_local * self.N * 4].contiguous().view(torch.float32).view(self.world, self.max_local, self.N)
+        done = rb[:, self.max_local * self.N * 4:]
+        if self.equal:
+            return rew.reshape(self.world * self.max_local, self.N), done.reshape(-1)
+        keep = self._keep
+        return rew.reshape(self.world * self.max_local, self.N)[keep], done.reshape(-1)[keep]
+
     def __call__(self, reward_local: torch.Tensor, done_local: torch.Tensor):
         """Blocking form: -> (reward [E_total, N], done [E_total]) on every rank."""
         self.start(reward_local, done_local)

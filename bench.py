@@ -187,6 +187,8 @@ def main():
         env.observe()  # main.py:88: first observation feeds the first action
 
     def one_step(t):
+        if gather is not None:
+            env.reward, env.done = gather.outputs(t % 2)
         if policy is not None:  # agent.get_action on the device, then api.step + env.update
             a_rot, a_ph = policy.act(env.obs, env.agent_state, env=env)
             env.step_update(a_rot, a_ph, None)
@@ -194,8 +196,9 @@ def main():
             env.step_update(rot[t % RING], ph[t % RING], None)
         if gather is not None:
             # the path's only exchange: the reward/done all-gather, one fused
-            # collective per step, left running under the next step's kernels
-            gather.start(env.reward, env.done)
+            # collective per step, left running under the next step's kernels.  The step wrote
+            # reward/done straight into the gather's send slot (no staging copy).
+            gather.start_slot(t % 2)
 
     for t in range(args.warmup):
         one_step(t)
@@ -210,7 +213,8 @@ def main():
 
     def barrier():
         if gather is not None:
-            gather.finish()  # the last step's gather belongs to the timed region
+            gather.finish_slot(0)  # the last steps' gathers belong to the timed region
+            gather.finish_slot(1)
         torch.cuda.synchronize(dev)
         if world > 1:
             dist.barrier()

@@ -44,7 +44,19 @@ def _worker(rank, world, port, E, N, q):
                 done.fill_(9)
                 r, d = g.finish()
             out.append((r.clone().numpy(), d.clone().numpy()))
-        q.put((rank, init["ants_xyt"], out))
+        # zero-copy form: the "kernels" write into the send slots, alternating
+        zc = []
+        for step in range(3):
+            rew, done = g.outputs(step % 2)
+            rew.copy_(torch.full((hi - lo, N), 10.0 + step) + torch.arange(lo, hi, dtype=torch.float32)[:, None])
+            done.copy_(torch.tensor([(e + step + 1) % 2 for e in range(lo, hi)], dtype=torch.uint8))
+            g.start_slot(step % 2)
+            if step > 0:
+                r, d = g.finish_slot((step - 1) % 2)
+                zc.append((r.clone().numpy(), d.clone().numpy()))
+        r, d = g.finish_slot(2 % 2)
+        zc.append((r.clone().numpy(), d.clone().numpy()))
+        q.put((rank, init["ants_xyt"], out, zc))
     finally:
         dist.destroy_process_group()
 
@@ -67,9 +79,11 @@ def test_sharded_envs_and_reward_gather(world, E):
     for step in range(3):
         want_r = np.full((E, N), float(step)) + np.arange(E, dtype=np.float32)[:, None]
         want_d = np.array([(e + step) % 2 for e in range(E)], np.uint8)
-        for _, _, out in res:  # every rank sees the whole batch
+        for _, _, out, zc in res:  # every rank sees the whole batch
             np.testing.assert_array_equal(out[step][0], want_r)
             np.testing.assert_array_equal(out[step][1], want_d)
+            np.testing.assert_array_equal(zc[step][0], want_r + 10.0)
+            np.testing.assert_array_equal(zc[step][1], 1 - want_d)
 
 
 def test_shard_range_partitions():
