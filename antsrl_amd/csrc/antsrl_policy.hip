@@ -28,6 +28,12 @@ typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 #define POL_KC 64                 // inputs per staged chunk (4 MFMA k-steps)
 #define POL_SROW (POL_KC + 8)     // bf16 per staged row: 144-byte stride = 16-byte aligned rows, 4-bank skew per row
 
+// bit shift that aligns the bf16 pair stream of POL_LOAD16: 16 when the element index of (row a, input k) is odd
+__device__ __forceinline__ uint32_t pol_shift(int a, int rows, int F, int k)
+{
+    return (((uint32_t)min(a, rows - 1) * (uint32_t)F + (uint32_t)k) & 1u) * 16u;
+}
+
 __device__ __forceinline__ void pol_wave_sync()
 {
     // LDS hand-off inside one wave: its LDS instructions execute in order, only the compiler must not reorder
@@ -56,7 +62,8 @@ k_policy_mlp(const float *__restrict__ obs, const float *__restrict__ agent_stat
 #pragma unroll
         for (int j = 0; j < POL_HIDDEN / 4; ++j) {
             const int row = (int)(threadIdx.x >> 6) + 4 * j;
-            wv[j] = k < IN ? w1[(size_t)row * IN + k] : 0.0f;
+            const float wl = w1[(size_t)row * IN + min(k, IN - 1)]; // unconditional (clamped) load, then select
+            wv[j] = k < IN ? wl : 0.0f;
         }
 #pragma unroll
         for (int j = 0; j < POL_HIDDEN / 4; ++j) w1s[((int)(threadIdx.x >> 6) + 4 * j) * KP + k] = (__bf16)wv[j];
@@ -73,10 +80,11 @@ k_policy_mlp(const float *__restrict__ obs, const float *__restrict__ agent_stat
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int hid = 16 * s + 8 * (j >> 2) + 4 * h + (j & 3);
-            float w = 0.0f;
-            if (r < 3) w = w2[r * POL_HIDDEN + hid];
-            else if (r < 6 && w3) w = w3[(r - 3) * POL_HIDDEN + hid];
-            a2[s][j] = (__bf16)w;
+            // unconditional loads on clamped rows + selects: a load inside a per-lane branch gets its own
+            // s_waitcnt vmcnt(0), i.e. 16 serial round trips in every workgroup's prologue
+            const float wa = w2[min(r, 2) * POL_HIDDEN + hid];
+            const float wb = w3 ? w3[min(max(r - 3, 0), 2) * POL_HIDDEN + hid] : 0.0f; // (w3 == NULL is uniform)
+            a2[s][j] = (__bf16)(r < 3 ? wa : (r < 6 ? wb : 0.0f));
         }
     float bias1[16];
 #pragma unroll
@@ -115,15 +123,19 @@ k_policy_mlp(const float *__restrict__ obs, const float *__restrict__ agent_stat
                 const int a = min(la + 4 * i, rows - 1);                                                 \
                     V[i] = *reinterpret_cast<const F4 *>(tile + (size_t)a * F + k_);                     \
             }                                                                                            \
-        } else if ((CH) < nchunks) { /* end of the row, the two agent_state inputs, zero pad */          \
+        } else if ((CH) < nchunks) { /* end of the row, the two agent_state inputs, zero pad.  Every load */ \
+            /* is UNCONDITIONAL on a clamped address and the choice is a select: with the loads inside    */ \
+            /* branches each one was followed by its own s_waitcnt vmcnt(0) - 48 serial round trips/tile */ \
             _Pragma("unroll") for (int i = 0; i < 8; ++i)                                                \
             {                                                                                            \
                 const int a = min(la + 4 * i, rows - 1);                                                 \
+                const float as0_ = agent_state[((size_t)t * 32 + a) * 2], as1_ = agent_state[((size_t)t * 32 + a) * 2 + 1]; \
+                float x_[4];                                                                             \
+                _Pragma("unroll") for (int j = 0; j < 4; ++j) x_[j] = tile[(size_t)a * F + min(k_ + j, F - 1)]; \
                 _Pragma("unroll") for (int j = 0; j < 4; ++j)                                            \
                 {                                                                                        \
                     const int kk = k_ + j;                                                               \
-                    V[i].v[j] = kk < F ? tile[(size_t)a * F + kk]                                        \
-                                       : (kk < IN ? agent_state[((size_t)t * 32 + a) * 2 + (kk - F)] : 0.0f); \
+                    V[i].v[j] = kk < F ? x_[j] : (kk == F ? as0_ : (kk == F + 1 ? as1_ : 0.0f));         \
                 }                                                                                        \
             }                                                                                            \
         }                                                                                                \
@@ -138,29 +150,38 @@ k_policy_mlp(const float *__restrict__ obs, const float *__restrict__ agent_stat
             _Pragma("unroll") for (int i = 0; i < 8; ++i)                                                \
             {                                                                                            \
                 const uint32_t ei = (uint32_t)min(la + 4 * i, rows - 1) * (uint32_t)F + (uint32_t)k_;    \
-                const uint32_t sh = (ei & 1u) * 16u;                                                     \
-                const D3 d = *reinterpret_cast<const D3 *>(reinterpret_cast<const uint32_t *>(tile16) + (ei >> 1)); \
-                V[i].x = __builtin_amdgcn_alignbit(d.v[1], d.v[0], sh);                                  \
-                V[i].y = __builtin_amdgcn_alignbit(d.v[2], d.v[1], sh);                                  \
+                /* RAW dwords: the funnel shift waits until the chunk is consumed (POL_PACK16), or the */ \
+                /* load would be waited for right here and nothing would be in flight                 */ \
+                V[i] = *reinterpret_cast<const D3 *>(reinterpret_cast<const uint32_t *>(tile16) + (ei >> 1)); \
             }                                                                                            \
-        } else if ((CH) < nchunks) { /* end of the row, the two agent_state inputs, zero pad */          \
+        } else if ((CH) < nchunks) { /* end of the row, the two agent_state inputs, zero pad: unconditional */ \
+            /* loads on clamped addresses + selects (see POL_LOAD), packed here                           */ \
             _Pragma("unroll") for (int i = 0; i < 8; ++i)                                                \
             {                                                                                            \
                 const int a = min(la + 4 * i, rows - 1);                                                 \
-                uint32_t e_[4];                                                                          \
+                const uint32_t as0_ = __builtin_bit_cast(uint16_t, (__bf16)agent_state[((size_t)t * 32 + a) * 2]);     \
+                const uint32_t as1_ = __builtin_bit_cast(uint16_t, (__bf16)agent_state[((size_t)t * 32 + a) * 2 + 1]); \
+                uint32_t x_[4], e_[4];                                                                   \
+                _Pragma("unroll") for (int j = 0; j < 4; ++j) x_[j] = tile16[(size_t)a * F + min(k_ + j, F - 1)]; \
                 _Pragma("unroll") for (int j = 0; j < 4; ++j)                                            \
                 {                                                                                        \
                     const int kk = k_ + j;                                                               \
-                    e_[j] = kk < F ? (uint32_t)tile16[(size_t)a * F + kk]                                \
-                                   : (kk < IN ? (uint32_t)__builtin_bit_cast(uint16_t, (__bf16)agent_state[((size_t)t * 32 + a) * 2 + (kk - F)]) : 0u); \
+                    e_[j] = kk < F ? x_[j] : (kk == F ? as0_ : (kk == F + 1 ? as1_ : 0u));               \
                 }                                                                                        \
-                V[i].x = e_[0] | (e_[1] << 16);                                                          \
-                V[i].y = e_[2] | (e_[3] << 16);                                                          \
+                V[i].v[0] = e_[0] | (e_[1] << 16);                                                       \
+                V[i].v[1] = e_[2] | (e_[3] << 16);                                                       \
+                V[i].v[2] = 0u;                                                                          \
             }                                                                                            \
         }                                                                                                \
     }
+        // the 4 packed elements of lane (la + 4 i, lf) of chunk CH, from the registers POL_LOAD16 filled
+#define POL_PACK16(V, CH, I)                                                                             \
+    (POL_KC * ((CH) + 1) + 2 <= F                                                                        \
+         ? make_uint2(__builtin_amdgcn_alignbit(V[I].v[1], V[I].v[0], pol_shift(la + 4 * (I), rows, F, POL_KC * (CH) + 4 * lf)), \
+                      __builtin_amdgcn_alignbit(V[I].v[2], V[I].v[1], pol_shift(la + 4 * (I), rows, F, POL_KC * (CH) + 4 * lf))) \
+         : make_uint2(V[I].v[0], V[I].v[1]))
         if constexpr (OBS16) {
-            uint2 q0[8], q1[8], q2[8];
+            D3 q0[8], q1[8], q2[8];
             POL_LOAD16(q0, 0)
             POL_LOAD16(q1, 1)
             for (int c = 0; c < nchunks; ++c) {
@@ -168,7 +189,7 @@ k_policy_mlp(const float *__restrict__ obs, const float *__restrict__ agent_stat
                 pol_wave_sync(); // the previous chunk's fragment reads are done
 #pragma unroll
                 for (int i = 0; i < 8; ++i)
-                    *reinterpret_cast<uint2 *>(stg + (la + 4 * i) * POL_SROW + 4 * lf) = q0[i];
+                    *reinterpret_cast<uint2 *>(stg + (la + 4 * i) * POL_SROW + 4 * lf) = POL_PACK16(q0, c, i);
                 pol_wave_sync();
                 const int s_end = min(ksteps - (POL_KC / 16) * c, POL_KC / 16);
                 for (int s = 0; s < s_end; ++s) {
@@ -208,6 +229,7 @@ k_policy_mlp(const float *__restrict__ obs, const float *__restrict__ agent_stat
         }
 #undef POL_LOAD
 #undef POL_LOAD16
+#undef POL_PACK16
         // acc[g] = hidden[(g&3) + 8*(g>>2) + 4*h] of ant r (before bias)
         f32x16 acc2;
 #pragma unroll
