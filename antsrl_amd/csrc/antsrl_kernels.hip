@@ -1147,8 +1147,11 @@ k_update_one(const KP p, const double *__restrict__ wall_jitter, const int out_b
     float act[C];
 #pragma unroll
     for (int c = 0; c < C; ++c) act[c] = p.s.activation[a * C + c];
-    const int32_t wc = (p.scaled && on) ? p.s.walldep_cell[a] : -1;
-    const int32_t dc = on ? p.s.dirty_cell[a] : -1;
+    // (unconditional loads on the clamped index + selects: a load inside a per-lane branch is followed by
+    // its own s_waitcnt vmcnt(0))
+    const int32_t wc_l = p.s.walldep_cell[a], dc_l = p.s.dirty_cell[a];
+    const int32_t wc = (p.scaled && on) ? wc_l : -1;
+    const int32_t dc = on ? dc_l : -1;
     const int ts = p.s.timestep[e] + 1; // environment.py:45
     if (tid < R) {
         rock[4 * tid + 0] = p.s.rock_cx[(size_t)e * R + tid];
