@@ -143,65 +143,81 @@ k_policy_mlp(const float *__restrict__ obs, const float *__restrict__ agent_stat
         // bfloat16 rows: 4 elements per lane and ant stay PACKED in two registers from the load to the LDS
         // tile (three ALIGNED dwords of the tile — its base is 64-byte aligned — and a funnel shift stand in
         // for a 2-byte aligned 8-byte load), which leaves room for two chunks in flight.
-#define POL_LOAD16(V, CH)                                                                                \
+#define POL_LOAD16_FULL(V, CH) /* chunk CH lies inside the rows (+ 4 bytes of read-ahead) */          \
     {                                                                                                    \
         const int k_ = POL_KC * (CH) + 4 * lf;                                                           \
-        if (POL_KC * ((CH) + 1) + 2 <= F) { /* chunk + the loader's 4 bytes of read-ahead inside the rows */ \
-            _Pragma("unroll") for (int i = 0; i < 8; ++i)                                                \
-            {                                                                                            \
-                const uint32_t ei = (uint32_t)min(la + 4 * i, rows - 1) * (uint32_t)F + (uint32_t)k_;    \
-                /* RAW dwords: the funnel shift waits until the chunk is consumed (POL_PACK16), or the */ \
-                /* load would be waited for right here and nothing would be in flight                 */ \
-                V[i] = *reinterpret_cast<const D3 *>(reinterpret_cast<const uint32_t *>(tile16) + (ei >> 1)); \
-            }                                                                                            \
-        } else if ((CH) < nchunks) { /* end of the row, the two agent_state inputs, zero pad: unconditional */ \
-            /* loads on clamped addresses + selects (see POL_LOAD), packed here                           */ \
-            _Pragma("unroll") for (int i = 0; i < 8; ++i)                                                \
-            {                                                                                            \
-                const int a = min(la + 4 * i, rows - 1);                                                 \
-                const uint32_t as0_ = __builtin_bit_cast(uint16_t, (__bf16)agent_state[((size_t)t * 32 + a) * 2]);     \
-                const uint32_t as1_ = __builtin_bit_cast(uint16_t, (__bf16)agent_state[((size_t)t * 32 + a) * 2 + 1]); \
-                uint32_t x_[4], e_[4];                                                                   \
-                _Pragma("unroll") for (int j = 0; j < 4; ++j) x_[j] = tile16[(size_t)a * F + min(k_ + j, F - 1)]; \
-                _Pragma("unroll") for (int j = 0; j < 4; ++j)                                            \
-                {                                                                                        \
-                    const int kk = k_ + j;                                                               \
-                    e_[j] = kk < F ? x_[j] : (kk == F ? as0_ : (kk == F + 1 ? as1_ : 0u));               \
-                }                                                                                        \
-                V[i].v[0] = e_[0] | (e_[1] << 16);                                                       \
-                V[i].v[1] = e_[2] | (e_[3] << 16);                                                       \
-                V[i].v[2] = 0u;                                                                          \
-            }                                                                                            \
+        _Pragma("unroll") for (int i = 0; i < 8; ++i)                                                    \
+        {                                                                                                \
+            const uint32_t ei = (uint32_t)min(la + 4 * i, rows - 1) * (uint32_t)F + (uint32_t)k_;        \
+            /* RAW dwords: the funnel shift waits until the chunk is consumed (POL_PACK16_FULL), or the */ \
+            /* load would be waited for right here and nothing would be in flight                      */ \
+            V[i] = *reinterpret_cast<const D3 *>(reinterpret_cast<const uint32_t *>(tile16) + (ei >> 1)); \
         }                                                                                                \
     }
-        // the 4 packed elements of lane (la + 4 i, lf) of chunk CH, from the registers POL_LOAD16 filled
-#define POL_PACK16(V, CH, I)                                                                             \
-    (POL_KC * ((CH) + 1) + 2 <= F                                                                        \
-         ? make_uint2(__builtin_amdgcn_alignbit(V[I].v[1], V[I].v[0], pol_shift(la + 4 * (I), rows, F, POL_KC * (CH) + 4 * lf)), \
-                      __builtin_amdgcn_alignbit(V[I].v[2], V[I].v[1], pol_shift(la + 4 * (I), rows, F, POL_KC * (CH) + 4 * lf))) \
-         : make_uint2(V[I].v[0], V[I].v[1]))
+#define POL_LOAD16_TAIL(V, CH) /* end of the row, the two agent_state inputs, zero pad: unconditional */ \
+    {                          /* loads on clamped addresses + selects (see POL_LOAD), packed here     */ \
+        const int k_ = POL_KC * (CH) + 4 * lf;                                                           \
+        _Pragma("unroll") for (int i = 0; i < 8; ++i)                                                    \
+        {                                                                                                \
+            const int a = min(la + 4 * i, rows - 1);                                                     \
+            const uint32_t as0_ = __builtin_bit_cast(uint16_t, (__bf16)agent_state[((size_t)t * 32 + a) * 2]);     \
+            const uint32_t as1_ = __builtin_bit_cast(uint16_t, (__bf16)agent_state[((size_t)t * 32 + a) * 2 + 1]); \
+            uint32_t x_[4], e_[4];                                                                       \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) x_[j] = tile16[(size_t)a * F + min(k_ + j, F - 1)]; \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                \
+            {                                                                                            \
+                const int kk = k_ + j;                                                                   \
+                e_[j] = kk < F ? x_[j] : (kk == F ? as0_ : (kk == F + 1 ? as1_ : 0u));                   \
+            }                                                                                            \
+            V[i].v[0] = e_[0] | (e_[1] << 16);                                                           \
+            V[i].v[1] = e_[2] | (e_[3] << 16);                                                           \
+            V[i].v[2] = 0u;                                                                              \
+        }                                                                                                \
+    }
+        // the 4 packed elements of lane (la + 4 i, lf) of chunk CH, from the registers the loaders filled
+#define POL_PACK16_FULL(V, CH, I)                                                                        \
+    make_uint2(__builtin_amdgcn_alignbit(V[I].v[1], V[I].v[0], pol_shift(la + 4 * (I), rows, F, POL_KC * (CH) + 4 * lf)), \
+               __builtin_amdgcn_alignbit(V[I].v[2], V[I].v[1], pol_shift(la + 4 * (I), rows, F, POL_KC * (CH) + 4 * lf)))
+#define POL_CONSUME16(CH, FULL)                                                                          \
+    {                                                                                                    \
+        pol_wave_sync(); /* the previous chunk's fragment reads are done */                              \
+        _Pragma("unroll") for (int i = 0; i < 8; ++i)                                                    \
+            *reinterpret_cast<uint2 *>(stg + (la + 4 * i) * POL_SROW + 4 * lf) =                         \
+                (FULL) ? POL_PACK16_FULL(q0, CH, i) : make_uint2(q0[i].v[0], q0[i].v[1]);                \
+        pol_wave_sync();                                                                                 \
+        const int s_end = min(ksteps - (POL_KC / 16) * (CH), POL_KC / 16);                               \
+        for (int s = 0; s < s_end; ++s) {                                                                \
+            const bf16x8 bfrag = *reinterpret_cast<const bf16x8 *>(stg + r * POL_SROW + 16 * s + 8 * h); \
+            const bf16x8 afrag = *reinterpret_cast<const bf16x8 *>(wrow + 16 * ((POL_KC / 16) * (CH) + s)); \
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag, acc, 0, 0, 0);                   \
+        }                                                                                                \
+    }
+        // register rotation BEFORE the next chunk is requested: copying q2 waits for the load issued one
+        // whole iteration ago, not for the one just issued
+#define POL_ROTATE16                                                                                     \
+    _Pragma("unroll") for (int i = 0; i < 8; ++i)                                                        \
+    {                                                                                                    \
+        q0[i] = q1[i];                                                                                   \
+        q1[i] = q2[i];                                                                                   \
+    }
         if constexpr (OBS16) {
+            // chunks [0, nfull) are whole; the steady-state loop below is BRANCH-FREE around its loads, so the
+            // compiler's vmcnt bookkeeping is exact and two chunks really are in flight (with the load
+            // kind chosen by an if / else inside the loop it falls back to waiting for nearly everything)
+            const int nfull = min(nchunks, max(0, (F - 2) / POL_KC));
             D3 q0[8], q1[8], q2[8];
-            POL_LOAD16(q0, 0)
-            POL_LOAD16(q1, 1)
-            for (int c = 0; c < nchunks; ++c) {
-                POL_LOAD16(q2, c + 2)
-                pol_wave_sync(); // the previous chunk's fragment reads are done
-#pragma unroll
-                for (int i = 0; i < 8; ++i)
-                    *reinterpret_cast<uint2 *>(stg + (la + 4 * i) * POL_SROW + 4 * lf) = POL_PACK16(q0, c, i);
-                pol_wave_sync();
-                const int s_end = min(ksteps - (POL_KC / 16) * c, POL_KC / 16);
-                for (int s = 0; s < s_end; ++s) {
-                    const bf16x8 bfrag = *reinterpret_cast<const bf16x8 *>(stg + r * POL_SROW + 16 * s + 8 * h);
-                    const bf16x8 afrag = *reinterpret_cast<const bf16x8 *>(wrow + 16 * ((POL_KC / 16) * c + s));
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag, acc, 0, 0, 0);
-                }
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    q0[i] = q1[i];
-                    q1[i] = q2[i];
-                }
+            if (nfull > 0) POL_LOAD16_FULL(q0, 0) else POL_LOAD16_TAIL(q0, 0)
+            if (nfull > 1) POL_LOAD16_FULL(q1, 1) else if (nchunks > 1) POL_LOAD16_TAIL(q1, 1)
+            int c = 0;
+            for (; c + 2 < nfull; ++c) {
+                if (c > 0) { POL_ROTATE16 }
+                POL_LOAD16_FULL(q2, c + 2)
+                POL_CONSUME16(c, true)
+            }
+            for (; c < nchunks; ++c) { // drain: at most the last two whole chunks and the partial ones
+                if (c > 0) { POL_ROTATE16 }
+                if (c + 2 < nchunks) POL_LOAD16_TAIL(q2, c + 2) // (c + 2 >= nfull here)
+                if (c < nfull) POL_CONSUME16(c, true) else POL_CONSUME16(c, false)
             }
         } else {
         F4 v[8], nx[8];
@@ -228,8 +244,11 @@ k_policy_mlp(const float *__restrict__ obs, const float *__restrict__ agent_stat
         }
         }
 #undef POL_LOAD
-#undef POL_LOAD16
-#undef POL_PACK16
+#undef POL_LOAD16_FULL
+#undef POL_LOAD16_TAIL
+#undef POL_PACK16_FULL
+#undef POL_CONSUME16
+#undef POL_ROTATE16
         // acc[g] = hidden[(g&3) + 8*(g>>2) + 4*h] of ant r (before bias)
         f32x16 acc2;
 #pragma unroll
