@@ -146,9 +146,16 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    # ANTSRL_BENCH_FORCE_DIST=1: run the N > 1 code path (RCCL process group, reward/done all-gather,
+    # max-over-ranks timing) with a single rank — a rehearsal of the multi-GPU launch on a one-GPU box
+    force_dist = world == 1 and os.environ.get("ANTSRL_BENCH_FORCE_DIST") == "1"
+    if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if force_dist:
+            os.environ.setdefault("MASTER_PORT", "29533")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)  # backend "nccl" is RCCL on ROCm
 
     from antsrl_amd import config as cm
@@ -176,7 +183,7 @@ def main():
     rot = torch.randint(-1, 2, (RING, E, cfg.n_ants), generator=g, device=dev, dtype=torch.int8)
     ph = torch.randint(0, 3, (RING, E, cfg.n_ants), generator=g, device=dev, dtype=torch.int8)
     gather = None
-    if world > 1:
+    if dist is not None:
         from antsrl_amd.dist import RewardGather
         gather = RewardGather(world * E, cfg.n_ants, dev)
 
@@ -216,7 +223,7 @@ def main():
             gather.finish_slot(0)  # the last steps' gathers belong to the timed region
             gather.finish_slot(1)
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if dist is not None:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -228,7 +235,7 @@ def main():
         one_step(args.warmup + t)
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if dist is not None:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -286,7 +293,7 @@ def main():
         out["config"]["device_reset_ms"] = round((time.perf_counter() - t1) * 1e3, 3)
     if evs:
         evs.destroy()
-    if world > 1:
+    if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
