@@ -430,9 +430,10 @@ extern "C" int antsrl_step_update(AntsHandle *h, const int8_t *rotation, const i
     if (timed) (void)hipEventRecord(h->ev[1], st);
     // Fuse Environment.update into the same launch unless the one-off wall clear of an initial
     // pheromone grid has to run between this step's observation and this update's deposits.
-    // Measured on MI355X (c3): fusing is SLOWER (0.44 vs 0.41 ms/step) — with two workgroups per CU
-    // the update's latency-bound phases idle half the CU, while as its own launch they overlap
-    // across all resident workgroups.  Kept selectable (ANTSRL_FUSE_UPDATE=1) for re-evaluation.
+    // Measured on MI355X (c3): fusing is within 1 % of two launches either way (0.325 vs 0.328 ms/step with
+    // the loop form of the update; the separate k_update_one has since become the faster kernel) — with
+    // two workgroups per CU the update's latency-bound phases idle half the CU.  Opt-in
+    // (ANTSRL_FUSE_UPDATE=1) for re-evaluation.
     static const bool want_fuse = getenv("ANTSRL_FUSE_UPDATE") && atoi(getenv("ANTSRL_FUSE_UPDATE")) != 0;
     const bool fuse = want_fuse && !(h->p.scaled && h->need_wall_clear);
     if (fuse && h->p.scaled && h->p.g_dep < 1e-20) { // re-base before the launch (value-preserving)

@@ -1941,11 +1941,12 @@ struct ActPlan {
     size_t lds;
 };
 
-// LDS budget: 160 KiB per CU.  Preference order is MEASURED (c3, MI355X): keeping the walls/anthill
-// bitmaps in LDS with two workgroups per CU (0.344 ms) beats three workgroups per CU that fetch
-// those bits through L1/L2 (0.382 ms) — the kernel is bound by its memory pipeline, not by
-// occupancy.  So: bitmaps in LDS at 3 then 2 workgroups per CU, only then the global-bitmap plans,
-// then one 1024-thread workgroup, then 512 threads with the whole CU's LDS.
+// LDS budget: 160 KiB per CU.  Preference order is MEASURED (c3, MI355X, profiles/plans.sh): the
+// walls/anthill bitmaps in LDS with two workgroups per CU (0.285 ms) beat the plans that fetch those
+// bits through L1/L2 (0.303 ms; a third workgroup per CU at 80 VGPRs does not raise the CU's
+// throughput either) and one 1024-thread workgroup (0.306-0.315 ms).  So: bitmaps in
+// LDS at 3 then 2 workgroups per CU, only then the global-bitmap plans, then one 1024-thread
+// workgroup, then 512 threads with the whole CU's LDS.
 // ANTSRL_ACT_PLAN=<n> pins candidate n (A/B runs).
 static ActPlan plan_act(const KP &p)
 {
