@@ -16,8 +16,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libantsrl_hip.so")
-SOURCES = ["antsrl_kernels.hip", "antsrl_capi.hip", "antsrl_policy.hip"]
-HEADERS = [os.path.join(CSRC, "antsrl_device.h"), os.path.join(HERE, "..", "include", "antsrl.h")]
+SOURCES = ["antsrl_act.hip", "antsrl_update.hip", "antsrl_sweep.hip", "antsrl_state.hip", "antsrl_capi.hip",
+           "antsrl_policy.hip"]
+HEADERS = [os.path.join(CSRC, h) for h in ("antsrl_device.h", "antsrl_util.h", "antsrl_update_env.h")] + [
+    os.path.join(HERE, "..", "include", "antsrl.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17",
          "-Wall", "-Wno-unused-function"]
 

@@ -1,7 +1,7 @@
 // antsrl_capi.hip — the C-ABI of libantsrl_hip.so (include/antsrl.h).
 //
 // Host-side only: validates the configuration, carves the caller's device workspace into the
-// state arrays of antsrl_device.h, and enqueues the kernels of antsrl_kernels.hip on the
+// state arrays of antsrl_device.h, and enqueues the kernels of antsrl_act / _update / _sweep / _state.hip on the
 // caller's stream.  No allocation, no synchronisation, no exceptions across the ABI.
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
@@ -13,7 +13,7 @@
 
 #include "antsrl_device.h"
 
-// launchers (antsrl_kernels.hip)
+// launchers (antsrl_act.hip, antsrl_update.hip, antsrl_sweep.hip, antsrl_state.hip)
 hipError_t antsrl_launch_act(const KP &p, const int8_t *rot, const int8_t *ph, int cur, float *obs,
                              float *agent_state, float *reward, uint8_t *done, int flags,
                              const double *jitter, int out_buf, hipStream_t st);

@@ -1,0 +1,284 @@
+// antsrl_state.hip — reset, device-side episode generator, activation, state read-out (not on the hot
+// path), launchers.
+#include "antsrl_util.h"
+
+// ===================================================================================
+// reset / state I/O (not on the hot path)
+// ===================================================================================
+__global__ void k_reset_ants(const KP p, const double *__restrict__ xyt, const double *__restrict__ seed)
+{
+    const size_t n = (size_t)p.E * p.N;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t e = i / p.N;
+        const double x = warp_coord(xyt[3 * i + 0], (double)p.W); // ants.py:27-30
+        const double y = warp_coord(xyt[3 * i + 1], (double)p.H);
+        p.s.x[i] = x; p.s.y[i] = y; p.s.theta[i] = xyt[3 * i + 2];
+        p.s.prev_x[i] = x; p.s.prev_y[i] = y;
+        p.s.holding[i] = 0.0f; p.s.prev_holding[i] = 0.0f;
+        p.s.mandibles[i] = 0; p.s.reward_state[i] = 0;
+        p.s.seed[i] = (float)seed[i];
+        p.s.dirty_cell[i] = -1;
+        p.s.walldep_cell[i] = -1;
+        for (int c = 0; c < p.C; ++c) p.s.activation[i * p.C + c] = 0.0f;
+        const double dx = x - (double)p.s.anthill_xyr[3 * e + 0], dy = y - (double)p.s.anthill_xyr[3 * e + 1];
+        p.s.prev_dist[i] = sqrt(dx * dx + dy * dy); // reward_custom.py:77
+    }
+}
+
+__global__ void k_reset_env(const KP p, const int32_t *__restrict__ xyr, const double *__restrict__ rocks)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= p.E) return;
+    for (int j = 0; j < 3; ++j) p.s.anthill_xyr[3 * e + j] = xyr[3 * e + j];
+    p.s.anthill_food[e] = 0.0;
+    p.s.timestep[e] = 1; // environment.py:27
+    p.s.reward_primed[e] = 0;
+    for (int q = 0; q < p.R; ++q) {
+        p.s.rock_cx[(size_t)e * p.R + q] = rocks[((size_t)e * p.R + q) * 4 + 0];
+        p.s.rock_cy[(size_t)e * p.R + q] = rocks[((size_t)e * p.R + q) * 4 + 1];
+        p.s.rock_r[(size_t)e * p.R + q] = rocks[((size_t)e * p.R + q) * 4 + 2];
+        p.s.rock_w[(size_t)e * p.R + q] = rocks[((size_t)e * p.R + q) * 4 + 3];
+    }
+}
+
+// bit-pack walls, rasterise the anthill disc (anthill.py:28-33), clear the explored map
+__global__ void k_reset_bits(const KP p, const uint8_t *__restrict__ walls, const int32_t *__restrict__ xyr)
+{
+    const size_t n = (size_t)p.E * p.words;
+    const size_t G = (size_t)p.W * p.H;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t e = i / p.words, w = i - e * p.words;
+        const long ax = xyr[3 * e + 0], ay = xyr[3 * e + 1], ar = xyr[3 * e + 2];
+        uint32_t wb = 0, ab = 0;
+        for (int b = 0; b < 32; ++b) {
+            const size_t cell = w * 32 + b;
+            if (cell >= G) break;
+            if (walls[e * G + cell]) wb |= 1u << b;
+            const long x = (long)(cell / p.H), y = (long)(cell % p.H);
+            // integer ax, ay, r: sqrt(d2) <= r  <=>  d2 <= r*r  (and r < 0 -> empty)
+            if (ar >= 0 && (ax - x) * (ax - x) + (ay - y) * (ay - y) <= ar * ar) ab |= 1u << b;
+        }
+        p.s.walls_bits[i] = wb;
+        p.s.area_bits[i] = ab;
+        p.s.explored_bits[i] = 0u;
+    }
+}
+
+__global__ void k_reset_grids(const KP p, const float *__restrict__ food, const float *__restrict__ phero)
+{
+    const size_t G = (size_t)p.W * p.H, n = (size_t)p.E * G;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t e = i / G, g = i - e * G;
+        p.s.food[i] = food[i];
+        for (int c = 0; c < p.C; ++c) {
+            const float v = phero ? phero[(e * p.C + c) * G + g] : 0.0f;
+            p.s.phero[0][i * p.C + c] = v;
+            p.s.phero[1][i * p.C + c] = v;
+        }
+    }
+}
+
+// ---- device-side episode generator (antsrl_generate) ----------------------
+// Draw `idx` of stream `tag` of environment `env`; the oracle (oracle_gen_u01) is bit-identical.
+#define GEN_SALT 0x6A09E667F3BCC909ULL
+enum { GEN_ANTHILL = 0, GEN_WALLS = 1, GEN_FOOD = 2, GEN_ROCKS = 3, GEN_ANT_ANGLE = 4, GEN_ANT_DIST = 5,
+       GEN_ANT_THETA = 6, GEN_ANT_SEED = 7 };
+__device__ __forceinline__ double gen_u01(uint64_t seed, uint32_t env, uint32_t tag, uint32_t idx)
+{
+    return jitter_u01(seed ^ GEN_SALT, env, tag, idx);
+}
+
+// per env: anthill (environment_generator.py:60-63), rocks (:77-85), food discs (map_generators.py:37-40)
+__global__ void k_gen_env(const KP p, const AntsGen g, const uint64_t seed)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= p.E) return;
+    const int W = p.W, H = p.H, m = W < H ? W : H;
+    p.s.anthill_xyr[3 * e + 0] = (int)(gen_u01(seed, e, GEN_ANTHILL, 0) * W * 0.5 + W * 0.25);
+    p.s.anthill_xyr[3 * e + 1] = (int)(gen_u01(seed, e, GEN_ANTHILL, 1) * H * 0.5 + H * 0.25);
+    p.s.anthill_xyr[3 * e + 2] = (int)(gen_u01(seed, e, GEN_ANTHILL, 2) * m * 0.05 + m * 0.05);
+    p.s.anthill_food[e] = 0.0;
+    p.s.timestep[e] = 1; // environment.py:27
+    p.s.reward_primed[e] = 0;
+    for (int q = 0; q < p.R; ++q) {
+        p.s.rock_cx[(size_t)e * p.R + q] = gen_u01(seed, e, GEN_ROCKS, 4 * q + 0) * (W * 0.75) + W * 0.25;
+        p.s.rock_cy[(size_t)e * p.R + q] = gen_u01(seed, e, GEN_ROCKS, 4 * q + 1) * (H * 0.25) + H * 0.25;
+        p.s.rock_r[(size_t)e * p.R + q] = gen_u01(seed, e, GEN_ROCKS, 4 * q + 2) * 5 + 5;
+        p.s.rock_w[(size_t)e * p.R + q] = gen_u01(seed, e, GEN_ROCKS, 4 * q + 3) * 50 + 50;
+    }
+    for (int d = 0; d < g.n_food_discs; ++d) {
+        int rad = (int)(gen_u01(seed, e, GEN_FOOD, 3 * d + 0) * (g.food_rmax - g.food_rmin) + g.food_rmin);
+        const int cap = (m - 1) / 2;
+        rad = rad > cap ? cap : rad;
+        int32_t *dd = p.s.gen_discs + ((size_t)e * ANTSRL_MAX_FOOD_DISCS + d) * 3;
+        dd[0] = rad;
+        dd[1] = (int)(gen_u01(seed, e, GEN_FOOD, 3 * d + 1) * (W - 2 * rad) + rad);
+        dd[2] = (int)(gen_u01(seed, e, GEN_FOOD, 3 * d + 2) * (H - 2 * rad) + rad);
+    }
+}
+
+// per 32-cell word: anthill area (anthill.py:28-33), walls cleared on it (:66-67), food discs zeroed
+// on walls (:71-72), empty pheromone and explored map
+__global__ void k_gen_cells(const KP p, const AntsGen g, const uint64_t seed)
+{
+    const size_t n = (size_t)p.E * p.words;
+    const size_t G = (size_t)p.W * p.H;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t e = i / p.words, w = i - e * p.words;
+        const long ax = p.s.anthill_xyr[3 * e + 0], ay = p.s.anthill_xyr[3 * e + 1], ar = p.s.anthill_xyr[3 * e + 2];
+        const int32_t *discs = p.s.gen_discs + e * ANTSRL_MAX_FOOD_DISCS * 3;
+        uint32_t wb = 0, ab = 0;
+        for (int b = 0; b < 32; ++b) {
+            const size_t cell = w * 32 + b;
+            if (cell >= G) break;
+            const long x = (long)(cell / p.H), y = (long)(cell % p.H);
+            const bool area = ar >= 0 && (ax - x) * (ax - x) + (ay - y) * (ay - y) <= ar * ar;
+            const bool wall = !area && gen_u01(seed, (uint32_t)e, GEN_WALLS, (uint32_t)cell) < g.wall_density;
+            bool fd = false;
+            for (int d = 0; d < g.n_food_discs; ++d) {
+                const long rad = discs[3 * d], dx = discs[3 * d + 1] - x, dy = discs[3 * d + 2] - y;
+                fd |= dx * dx + dy * dy <= rad * rad;
+            }
+            if (area) ab |= 1u << b;
+            if (wall) wb |= 1u << b;
+            p.s.food[e * G + cell] = (fd && !wall) ? 1.0f : 0.0f;
+            for (int c = 0; c < p.C; ++c) {
+                p.s.phero[0][(e * G + cell) * p.C + c] = 0.0f;
+                p.s.phero[1][(e * G + cell) * p.C + c] = 0.0f;
+            }
+        }
+        p.s.walls_bits[i] = wb;
+        p.s.area_bits[i] = ab;
+        p.s.explored_bits[i] = 0u;
+    }
+}
+
+// per ant: placement around the anthill (environment_generator.py:87-93), then Ants.__init__
+__global__ void k_gen_ants(const KP p, const uint64_t seed)
+{
+    const size_t n = (size_t)p.E * p.N;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const uint32_t e = (uint32_t)(i / p.N), a = (uint32_t)(i - (size_t)e * p.N);
+        const double ax = (double)p.s.anthill_xyr[3 * e + 0], ay = (double)p.s.anthill_xyr[3 * e + 1];
+        const double ar = (double)p.s.anthill_xyr[3 * e + 2];
+        const double ang = gen_u01(seed, e, GEN_ANT_ANGLE, a) * 2 * PI_D;
+        const double dist = gen_u01(seed, e, GEN_ANT_DIST, a) * ar * 0.8;
+        const double x = warp_coord(cos(ang) * dist + ax, (double)p.W);
+        const double y = warp_coord(sin(ang) * dist + ay, (double)p.H);
+        p.s.x[i] = x; p.s.y[i] = y;
+        p.s.theta[i] = gen_u01(seed, e, GEN_ANT_THETA, a) * 2 * PI_D;
+        p.s.prev_x[i] = x; p.s.prev_y[i] = y;
+        p.s.holding[i] = 0.0f; p.s.prev_holding[i] = 0.0f;
+        p.s.mandibles[i] = 0; p.s.reward_state[i] = 0;
+        p.s.seed[i] = (float)gen_u01(seed, e, GEN_ANT_SEED, a);
+        p.s.dirty_cell[i] = -1;
+        p.s.walldep_cell[i] = -1;
+        for (int c = 0; c < p.C; ++c) p.s.activation[i * p.C + c] = 0.0f;
+        const double dx = x - ax, dy = y - ay;
+        p.s.prev_dist[i] = sqrt(dx * dx + dy * dy); // reward_custom.py:77
+    }
+}
+
+__global__ void k_set_activation(const KP p, const float *__restrict__ act)
+{
+    const size_t n = (size_t)p.E * p.N * p.C;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        p.s.activation[i] = act[i];
+}
+
+__global__ void k_read_state(const KP p, const int which, const int cur, void *__restrict__ dstv)
+{
+    const size_t EN = (size_t)p.E * p.N, G = (size_t)p.W * p.H, EG = (size_t)p.E * G;
+    const size_t stride = (size_t)gridDim.x * blockDim.x, t0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    switch (which) {
+    case ANTSRL_S_ANTS_XYT:
+        for (size_t i = t0; i < EN; i += stride) {
+            double *d = (double *)dstv + 3 * i;
+            d[0] = p.s.x[i]; d[1] = p.s.y[i]; d[2] = p.s.theta[i];
+        }
+        break;
+    case ANTSRL_S_PREV_XY:
+        for (size_t i = t0; i < EN; i += stride) {
+            ((double *)dstv)[2 * i] = p.s.prev_x[i];
+            ((double *)dstv)[2 * i + 1] = p.s.prev_y[i];
+        }
+        break;
+    case ANTSRL_S_HOLDING: for (size_t i = t0; i < EN; i += stride) ((float *)dstv)[i] = p.s.holding[i]; break;
+    case ANTSRL_S_SEED: for (size_t i = t0; i < EN; i += stride) ((float *)dstv)[i] = p.s.seed[i]; break;
+    case ANTSRL_S_MANDIBLES: for (size_t i = t0; i < EN; i += stride) ((uint8_t *)dstv)[i] = p.s.mandibles[i]; break;
+    case ANTSRL_S_REWARD_STATE: for (size_t i = t0; i < EN; i += stride) ((uint8_t *)dstv)[i] = p.s.reward_state[i]; break;
+    case ANTSRL_S_ACTIVATION:
+        for (size_t i = t0; i < EN * p.C; i += stride) ((float *)dstv)[i] = p.s.activation[i];
+        break;
+    case ANTSRL_S_PHERO: // interleaved [E][G][C] -> canonical [E][C][G]
+        for (size_t i = t0; i < EG * p.C; i += stride) {
+            const size_t e = i / (G * p.C), rem = i - e * G * p.C, c = rem / G, g = rem - c * G;
+            float v = p.s.phero[cur][(e * G + g) * p.C + c];
+            if (p.scaled) {
+                v *= (float)p.g_now;
+                if (v < (float)p.threshold) v = 0.0f;
+            }
+            ((float *)dstv)[i] = v;
+        }
+        break;
+    case ANTSRL_S_FOOD: for (size_t i = t0; i < EG; i += stride) ((float *)dstv)[i] = p.s.food[i]; break;
+    case ANTSRL_S_EXPLORED:
+    case ANTSRL_S_WALLS:
+    case ANTSRL_S_ANTHILL_AREA: {
+        const uint32_t *bits = which == ANTSRL_S_EXPLORED ? p.s.explored_bits
+                               : which == ANTSRL_S_WALLS  ? p.s.walls_bits : p.s.area_bits;
+        for (size_t i = t0; i < EG; i += stride) {
+            const size_t e = i / G, g = i - e * G;
+            ((uint8_t *)dstv)[i] = (uint8_t)test_bit(bits + e * p.words, (uint32_t)g);
+        }
+    } break;
+    case ANTSRL_S_ANTHILL_FOOD: for (size_t i = t0; i < (size_t)p.E; i += stride) ((double *)dstv)[i] = p.s.anthill_food[i]; break;
+    case ANTSRL_S_TIMESTEP: for (size_t i = t0; i < (size_t)p.E; i += stride) ((int32_t *)dstv)[i] = p.s.timestep[i]; break;
+    case ANTSRL_S_ANTHILL_XYR: for (size_t i = t0; i < (size_t)p.E * 3; i += stride) ((int32_t *)dstv)[i] = p.s.anthill_xyr[i]; break;
+    case ANTSRL_S_ROCK_RW:
+        for (size_t i = t0; i < (size_t)p.E * p.R; i += stride) {
+            ((double *)dstv)[2 * i] = p.s.rock_r[i];
+            ((double *)dstv)[2 * i + 1] = p.s.rock_w[i];
+        }
+        break;
+    case ANTSRL_S_ROCK_CENTERS:
+        for (size_t i = t0; i < (size_t)p.E * p.R; i += stride) {
+            ((double *)dstv)[2 * i] = p.s.rock_cx[i];
+            ((double *)dstv)[2 * i + 1] = p.s.rock_cy[i];
+        }
+        break;
+    default: break;
+    }
+}
+
+// host-side launchers (called from antsrl_capi.hip)
+hipError_t antsrl_launch_reset(const KP &p, const AntsInit *in, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_reset_env, dim3((p.E + 255) / 256), dim3(256), 0, st, p, in->anthill_xyr, in->rocks);
+    hipLaunchKernelGGL(k_reset_ants, dim3(grid_for((size_t)p.E * p.N)), dim3(256), 0, st, p, in->ants_xyt, in->seed);
+    hipLaunchKernelGGL(k_reset_bits, dim3(grid_for((size_t)p.E * p.words)), dim3(256), 0, st, p, in->walls,
+                       in->anthill_xyr);
+    hipLaunchKernelGGL(k_reset_grids, dim3(grid_for((size_t)p.E * p.W * p.H)), dim3(256), 0, st, p, in->food,
+                       in->phero);
+    return hipGetLastError();
+}
+
+hipError_t antsrl_launch_generate(const KP &p, const AntsGen &g, uint64_t seed, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_gen_env, dim3((p.E + 255) / 256), dim3(256), 0, st, p, g, seed);
+    hipLaunchKernelGGL(k_gen_cells, dim3(grid_for((size_t)p.E * p.words)), dim3(256), 0, st, p, g, seed);
+    hipLaunchKernelGGL(k_gen_ants, dim3(grid_for((size_t)p.E * p.N)), dim3(256), 0, st, p, seed);
+    return hipGetLastError();
+}
+
+hipError_t antsrl_launch_set_activation(const KP &p, const float *act, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_set_activation, dim3(grid_for((size_t)p.E * p.N * p.C)), dim3(256), 0, st, p, act);
+    return hipGetLastError();
+}
+
+hipError_t antsrl_launch_read_state(const KP &p, int which, int cur, void *dst, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_read_state, dim3(grid_for((size_t)p.E * p.W * p.H)), dim3(256), 0, st, p, which, cur, dst);
+    return hipGetLastError();
+}

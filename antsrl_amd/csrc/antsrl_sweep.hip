@@ -1,0 +1,407 @@
+// antsrl_sweep.hip — pheromone sweeps: k_sweep0 (radius 0, streaming), k_sweep_march (radius 1..3,
+// register-marching stencil, separable form for rank-1 filters), k_sweep_tiled (float64 cross-check),
+// the wall clear / re-basing passes of the scaled representation, launchers.
+#include "antsrl_util.h"
+
+// ===================================================================================
+// Pheromone sweep — Walls zeroing (walls.py:30) + Pheromone.update (pheromone.py:43-45)
+// + the whole-grid clip of add_pheromones (pheromone.py:40-41; min is idempotent and the
+// deposit is non-negative, so clipping before the deposit and again at the deposit gives the
+// same grid).
+// ===================================================================================
+// Radius 0 (the shipped DIFFUSE_FACTOR = 0 filter): out = thresh(in * f0), pure streaming,
+// 16 bytes per lane per access.  The product is formed in float64 so that the coefficient
+// (0.999) carries no float32 rounding bias across thousands of steps.
+#define SW0_UNROLL 4
+template <int C>
+__global__ void __launch_bounds__(256)
+k_sweep0(const KP p, const float *__restrict__ in, float *__restrict__ out)
+{
+    // grid = (ceil(per_env / (256*SW0_UNROLL)), E): no per-thread division by the env size
+    const uint32_t per_env = (uint32_t)((size_t)p.W * p.H * C / 4); // float4 per env
+    const size_t e = blockIdx.y;
+    const uint32_t *walls = p.s.walls_bits + e * p.words;
+    const float4 *src = reinterpret_cast<const float4 *>(in) + e * per_env;
+    float4 *dst = reinterpret_cast<float4 *>(out) + e * per_env;
+    const double f0 = p.filter[0], thr = p.threshold;
+    const float mx = (float)p.max_val;
+    const bool clip = p.has_max_val && p.N > 0;
+    const uint32_t v0 = blockIdx.x * (256 * SW0_UNROLL) + threadIdx.x;
+    float4 a[SW0_UNROLL];
+#pragma unroll
+    for (int u = 0; u < SW0_UNROLL; ++u) {
+        const uint32_t v = v0 + u * 256;
+        if (v < per_env) a[u] = src[v];
+    }
+#pragma unroll
+    for (int u = 0; u < SW0_UNROLL; ++u) {
+        const uint32_t v = v0 + u * 256;
+        if (v >= per_env) continue;
+        float r[4] = {a[u].x, a[u].y, a[u].z, a[u].w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t cell = (v * 4 + j) / C;
+            const double o = (double)r[j] * f0;
+            float f = (o < thr) ? 0.0f : (float)o;
+            if (test_bit(walls, cell)) f = 0.0f;
+            if (clip) f = fminf(f, mx);
+            r[j] = f;
+        }
+        store_stream(dst + v, make_float4(r[0], r[1], r[2], r[3]));
+    }
+}
+
+// scalar fallback for grids whose float count per env is not a multiple of 4
+template <int C>
+__global__ void __launch_bounds__(256)
+k_sweep0_scalar(const KP p, const float *__restrict__ in, float *__restrict__ out, const size_t n)
+{
+    const size_t per_env = (size_t)p.W * p.H * C;
+    const double f0 = p.filter[0], thr = p.threshold;
+    const bool clip = p.has_max_val && p.N > 0;
+    for (size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x; v < n; v += (size_t)gridDim.x * blockDim.x) {
+        const size_t e = v / per_env;
+        const uint32_t cell = (uint32_t)((v - e * per_env) / C);
+        const double o = (double)in[v] * f0;
+        float f = (o < thr) ? 0.0f : (float)o;
+        if (test_bit(p.s.walls_bits + e * p.words, cell)) f = 0.0f;
+        if (clip) f = fminf(f, (float)p.max_val);
+        out[v] = f;
+    }
+}
+
+// Radius 1..3: LDS-tiled 2-D convolution with zero-fill boundary,
+// scipy.signal.convolve2d(phero, F, 'same', 'fill', 0)  (pheromone.py:44):
+//   out[x,y] = sum_{a,b} F[a,b] * in[x-a+r, y-b+r]   (true convolution: kernel flipped)
+// The wall mask is applied while the tile is staged (walls.py:30 zeroes the INPUT of the
+// convolution, so a wall cell still receives its neighbours' diffusion).
+#define SW_TX 16
+#define SW_TY 64
+template <int C>
+__global__ void __launch_bounds__(256)
+k_sweep_tiled(const KP p, const float *__restrict__ in, float *__restrict__ out)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    float *tile = (float *)smem;
+    const int fr = p.filter_radius, fs = 2 * fr + 1;
+    const int LX = SW_TX + 2 * fr, LY = SW_TY + 2 * fr;
+    const int e = blockIdx.z, x0 = blockIdx.y * SW_TX, y0 = blockIdx.x * SW_TY;
+    const int W = p.W, H = p.H;
+    const size_t G = (size_t)W * H;
+    const float *src = in + (size_t)e * G * C;
+    float *dst = out + (size_t)e * G * C;
+    const uint32_t *walls = p.s.walls_bits + (size_t)e * p.words;
+    for (int t = threadIdx.x; t < LX * LY; t += blockDim.x) {
+        const int lx = t / LY, ly = t - lx * LY;
+        const int gx = x0 + lx - fr, gy = y0 + ly - fr;
+        const bool inside = gx >= 0 && gx < W && gy >= 0 && gy < H;
+        const uint32_t cell = inside ? (uint32_t)(gx * H + gy) : 0u;
+        const bool live = inside && !test_bit(walls, cell);
+#pragma unroll
+        for (int c = 0; c < C; ++c) tile[(size_t)t * C + c] = live ? src[(size_t)cell * C + c] : 0.0f;
+    }
+    __syncthreads();
+    const bool clip = p.has_max_val && p.N > 0;
+    for (int t = threadIdx.x; t < SW_TX * SW_TY; t += blockDim.x) {
+        const int lx = t / SW_TY, ly = t - lx * SW_TY;
+        const int gx = x0 + lx, gy = y0 + ly;
+        if (gx >= W || gy >= H) continue;
+        double acc[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) acc[c] = 0.0;
+        for (int a = 0; a < fs; ++a)
+            for (int b = 0; b < fs; ++b) {
+                const double f = p.filter[a * fs + b];
+                const float *tp = tile + ((size_t)(lx - a + 2 * fr) * LY + (ly - b + 2 * fr)) * C;
+#pragma unroll
+                for (int c = 0; c < C; ++c) acc[c] += f * (double)tp[c];
+            }
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            float f = (acc[c] < p.threshold) ? 0.0f : (float)acc[c];
+            if (clip) f = fminf(f, (float)p.max_val);
+            dst[((size_t)gx * H + gy) * C + c] = f;
+        }
+    }
+}
+
+// Scaled mode helpers (rare, full-grid): zero the wall cells of the grid (first update after a
+// reset that supplied an initial pheromone grid) and re-base the units when f0^S gets tiny.
+__global__ void __launch_bounds__(256) k_phero_wall_clear(const KP p)
+{
+    const size_t G = (size_t)p.W * p.H, n = (size_t)p.E * G;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t e = i / G, g = i - e * G;
+        if (test_bit(p.s.walls_bits + e * p.words, (uint32_t)g))
+            for (int c = 0; c < p.C; ++c) p.s.phero[0][i * p.C + c] = 0.0f;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_phero_renorm(const KP p)
+{
+    // u := materialised value (units of f0^0); the host then restarts S at 0.
+    const size_t n = (size_t)p.E * p.W * p.H * p.C;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const double v = (double)p.s.phero[0][i] * p.g_now;
+        p.s.phero[0][i] = v < p.threshold ? 0.0f : (float)v;
+    }
+}
+
+// Radius 1..3, main kernel: register-marching stencil.  One wave owns a strip of 64-2R output
+// columns (lane <-> column y, R halo lanes each side) of one environment and marches down the
+// x rows in blocks of S = 2R+1 rows: every input row is read ONCE, coalesced, straight into
+// registers (all S rows of a block are in flight together, no branch between them); its 2R
+// y-neighbours come from the other lanes of the wave (__shfl); the 2S-1 output rows a block
+// touches are running accumulators in registers.  No LDS, no re-reads except the 2R halo columns.
+//   out[x,y] = sum_{a,b} F[a,b] * in[x-a+R, y-b+R]      (convolve2d 'same', zero fill)
+// Arithmetic: fp32 FMAs with the taps split hi+lo (see KP::ftap) — unbiased to ~1e-15 per step.
+// Loop order b -> a -> row keeps only one tap column (2S scalars) live at a time.
+// lane i <- lane i - 1 / lane i + 1 across the whole wave (zero shifted in at the ends)
+__device__ __forceinline__ float wave_shr1(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float wave_shl1(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xF, 0xF, true));
+}
+
+// SEP: the filter is rank-1, F[a][b] = u[a] v[b] (KP::fsep_u / fsep_v): each input row is first
+// convolved across the lanes with v (S shuffles), the result feeds the S running output rows with u —
+// 4 S FMAs per input value instead of 2 S^2.
+template <int C, int R, bool SEP>
+__global__ void __launch_bounds__(256)
+k_sweep_march(const KP p, const float *__restrict__ in, float *__restrict__ out, const int seg_rows)
+{
+    constexpr int S = 2 * R + 1, OUTW = 64 - 2 * R, NA = 2 * S - 1;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int e = blockIdx.y, W = p.W, H = p.H;
+    const int strip = blockIdx.x * 4 + wave;
+    // The S*S taps {hi, lo} sit in LDS and are read back (uniform address = broadcast) right where
+    // they are used: ~100 wave-uniform scalars do not fit the SGPR file — as kernel arguments the
+    // compiler hoists them out of the march and spills them through v_writelane/v_readlane.
+    __shared__ float taps[2 * ANTSRL_MAX_FILTER_TAPS];
+    if (!SEP && threadIdx.x < 2 * S * S) taps[threadIdx.x] = p.ftap[threadIdx.x];
+    if (SEP && threadIdx.x < 2 * S) {
+        taps[threadIdx.x] = p.fsep_u[threadIdx.x];
+        taps[2 * S + threadIdx.x] = p.fsep_v[threadIdx.x];
+    }
+    __syncthreads();
+    if (strip * OUTW >= H) return; // whole wave (no further barriers)
+    const int y = strip * OUTW - R + lane;
+    const bool col_in = y >= 0 && y < H;
+    const bool col_out = lane >= R && lane < 64 - R && y < H;
+    const int yc = col_in ? y : 0;
+    const float colmask = col_in ? 1.0f : 0.0f;
+    const size_t G = (size_t)W * H;
+    const float *src = in + (size_t)e * G * C;
+    float *dst = out + (size_t)e * G * C;
+    const uint32_t *walls = p.s.walls_bits + (size_t)e * p.words;
+    const bool clip = p.has_max_val && p.N > 0;
+    const float thr = (float)p.threshold, mx = (float)p.max_val;
+    // acc[j] accumulates output row x = xi0 - R + j of the current block
+    float acc[NA][C];
+#pragma unroll
+    for (int j = 0; j < NA; ++j)
+#pragma unroll
+        for (int c = 0; c < C; ++c) acc[j][c] = 0.0f;
+
+    // This wave produces output rows [x_lo, x_hi): it marches input rows x_lo - R .. x_hi - 1 + R
+    // (rows outside the grid count as zero), i.e. 2R rows of overlap with its x-neighbour segment.
+    const int x_lo = blockIdx.z * seg_rows, x_hi = min(x_lo + seg_rows, W);
+    // one block of S rows is always in flight ahead of the block being accumulated
+    float nv[S][C];
+    uint32_t nword[S], ncell[S];
+#define MARCH_LOAD(XI0)                                                                              \
+    {                                                                                                \
+        _Pragma("unroll") for (int s = 0; s < S; ++s)                                                \
+        {                                                                                            \
+            const int xc = min(max((XI0) + s, 0), W - 1); /* clamped; masked to zero below */        \
+            ncell[s] = (uint32_t)(xc * H + yc);                                                      \
+            nword[s] = walls[ncell[s] >> 5];                                                         \
+        }                                                                                            \
+        _Pragma("unroll") for (int s = 0; s < S; ++s)                                                \
+        {                                                                                            \
+            if (C == 2) {                                                                            \
+                const float2 t = *reinterpret_cast<const float2 *>(src + (size_t)ncell[s] * 2);      \
+                nv[s][0] = t.x; nv[s][C - 1] = t.y;                                                  \
+            } else {                                                                                 \
+                _Pragma("unroll") for (int c = 0; c < C; ++c) nv[s][c] = src[(size_t)ncell[s] * C + c]; \
+            }                                                                                        \
+        }                                                                                            \
+    }
+    MARCH_LOAD(x_lo - R)
+    for (int xi0 = x_lo - R; xi0 < x_hi + R; xi0 += S) {
+        float v[S][C];
+        uint32_t wword[S];
+        uint32_t cellv[S];
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            cellv[s] = ncell[s]; wword[s] = nword[s];
+#pragma unroll
+            for (int c = 0; c < C; ++c) v[s][c] = nv[s][c];
+        }
+        MARCH_LOAD(xi0 + S) // prefetch (clamped addresses: a harmless re-read past the end)
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            // zero fill outside the grid, and walls.py:30 zeroes the INPUT of the convolution.
+            // Arithmetic masks (0/1 factors) rather than selects: lane-mask booleans would each
+            // occupy an SGPR pair and spill.
+            const float keep = colmask * (float)(1u - ((wword[s] >> (cellv[s] & 31)) & 1u)) *
+                               ((xi0 + s >= 0 && xi0 + s < W) ? 1.0f : 0.0f);
+#pragma unroll
+            for (int c = 0; c < C; ++c) v[s][c] *= keep;
+        }
+        // ---- accumulate: input row s feeds output row j = s + a (x = xi0 + s + a - R).
+        //      The tap-column loop is a REAL loop (not unrolled): only one column's 2S taps are live,
+        //      so nothing tempts the compiler to hoist ~100 scalars out of the march and spill them.
+        if (SEP) {
+            float hrow[S][C]; // input row s convolved across the lanes with v
+            // neighbours by whole-wave DPP shifts of one lane (v_mov_b32_dpp wave_shr:1 / wave_shl:1, a VALU
+            // move) instead of ds_bpermute: the LDS pipe stays out of the inner loop
+#pragma unroll
+            for (int s = 0; s < S; ++s)
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    float h = fmaf(taps[2 * S + 2 * R], v[s][c], 0.0f);
+                    h = fmaf(taps[2 * S + 2 * R + 1], v[s][c], h);
+                    float up = v[s][c], dn = v[s][c]; // up: value of lane - d, dn: value of lane + d
+#pragma unroll
+                    for (int d = 1; d <= R; ++d) {
+                        up = wave_shr1(up);
+                        dn = wave_shl1(dn);
+                        h = fmaf(taps[2 * S + 2 * (R + d)], up, h);
+                        h = fmaf(taps[2 * S + 2 * (R + d) + 1], up, h);
+                        h = fmaf(taps[2 * S + 2 * (R - d)], dn, h);
+                        h = fmaf(taps[2 * S + 2 * (R - d) + 1], dn, h);
+                    }
+                    hrow[s][c] = h;
+                }
+#pragma unroll
+            for (int a = 0; a < S; ++a) {
+                const float uh = taps[2 * a], ul = taps[2 * a + 1];
+#pragma unroll
+                for (int s = 0; s < S; ++s)
+#pragma unroll
+                    for (int c = 0; c < C; ++c) {
+                        acc[s + a][c] = fmaf(uh, hrow[s][c], acc[s + a][c]);
+                        acc[s + a][c] = fmaf(ul, hrow[s][c], acc[s + a][c]);
+                    }
+            }
+        } else
+#pragma unroll 1
+        for (int b = 0; b < S; ++b) {
+            float sh[S][C]; // sh[s] = in[xi0+s][y - b + R]
+#pragma unroll
+            for (int s = 0; s < S; ++s)
+#pragma unroll
+                for (int c = 0; c < C; ++c) sh[s][c] = __shfl(v[s][c], lane - (b - R));
+            const float *tp = taps + 2 * b * S;
+#pragma unroll
+            for (int a = 0; a < S; ++a) {
+                const float fh = tp[2 * a], fl = tp[2 * a + 1]; // LDS, uniform address: broadcast
+#pragma unroll
+                for (int s = 0; s < S; ++s)
+#pragma unroll
+                    for (int c = 0; c < C; ++c) {
+                        acc[s + a][c] = fmaf(fh, sh[s][c], acc[s + a][c]);
+                        acc[s + a][c] = fmaf(fl, sh[s][c], acc[s + a][c]);
+                    }
+            }
+        }
+        // ---- rows j = 0..S-1 are complete (last contributor: input row xi0 + j, tap row 0)
+#pragma unroll
+        for (int j = 0; j < S; ++j) {
+            const int x = xi0 - R + j;
+            if (x >= x_lo && x < x_hi && col_out) {
+                float r[C];
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    float f = acc[j][c] < thr ? 0.0f : acc[j][c]; // pheromone.py:45
+                    if (clip) f = fminf(f, mx);
+                    r[c] = f;
+                }
+                const size_t o = ((size_t)x * H + y) * C;
+                if (C == 2) {
+                    // streaming store (see store_stream): the next reader is a later kernel
+                    typedef float vf2_t __attribute__((ext_vector_type(2)));
+                    __builtin_nontemporal_store(vf2_t{r[0], r[C - 1]}, reinterpret_cast<vf2_t *>(dst + o));
+                } else {
+#pragma unroll
+                    for (int c = 0; c < C; ++c) dst[o + c] = r[c];
+                }
+            }
+        }
+        // carry the S-1 partial rows over to the next block
+#pragma unroll
+        for (int j = 0; j < NA; ++j)
+#pragma unroll
+            for (int c = 0; c < C; ++c) acc[j][c] = (j + S < NA) ? acc[j + S][c] : 0.0f;
+    }
+#undef MARCH_LOAD
+}
+
+// host-side launchers (called from antsrl_capi.hip)
+template <int C>
+static hipError_t launch_sweep_c(const KP &p, int cur, hipStream_t st)
+{
+    const float *in = p.s.phero[cur];
+    float *out = p.s.phero[cur ^ 1];
+    const size_t n = (size_t)p.E * p.W * p.H * C;
+    if (p.filter_radius == 0) {
+        if (((size_t)p.W * p.H * C) % 4 == 0) {
+            const size_t per_env4 = (size_t)p.W * p.H * C / 4;
+            const unsigned bx = (unsigned)((per_env4 + 256 * SW0_UNROLL - 1) / (256 * SW0_UNROLL));
+            hipLaunchKernelGGL((k_sweep0<C>), dim3(bx, (unsigned)p.E), dim3(256), 0, st, p, in, out);
+        } else {
+            size_t blocks = (n + 255) / 256;
+            if (blocks > 256 * 64) blocks = 256 * 64;
+            hipLaunchKernelGGL((k_sweep0_scalar<C>), dim3((unsigned)blocks), dim3(256), 0, st, p, in, out, n);
+        }
+    } else if (!getenv("ANTSRL_SWEEP_TILED")) {
+        const int fr = p.filter_radius;
+        const int strips = (p.H + (64 - 2 * fr) - 1) / (64 - 2 * fr);
+        // split the march along x into segments of >= 64 rows until the chip has ~16 waves per SIMD
+        // to choose from (each extra segment re-reads 2R rows)
+        int nseg = 1;
+        while ((long long)p.E * strips * nseg < 16 * 1024 && p.W / (nseg * 2) >= 64) nseg *= 2;
+        const int seg_rows = (p.W + nseg - 1) / nseg;
+        dim3 grid((strips + 3) / 4, p.E, (p.W + seg_rows - 1) / seg_rows);
+        if (p.filter_sep) {
+            if (fr == 1) hipLaunchKernelGGL((k_sweep_march<C, 1, true>), grid, dim3(256), 0, st, p, in, out, seg_rows);
+            else if (fr == 2) hipLaunchKernelGGL((k_sweep_march<C, 2, true>), grid, dim3(256), 0, st, p, in, out, seg_rows);
+            else hipLaunchKernelGGL((k_sweep_march<C, 3, true>), grid, dim3(256), 0, st, p, in, out, seg_rows);
+        } else if (fr == 1) hipLaunchKernelGGL((k_sweep_march<C, 1, false>), grid, dim3(256), 0, st, p, in, out, seg_rows);
+        else if (fr == 2) hipLaunchKernelGGL((k_sweep_march<C, 2, false>), grid, dim3(256), 0, st, p, in, out, seg_rows);
+        else hipLaunchKernelGGL((k_sweep_march<C, 3, false>), grid, dim3(256), 0, st, p, in, out, seg_rows);
+    } else { // LDS-tiled float64 reference variant (A/B and cross-check: ANTSRL_SWEEP_TILED=1)
+        const int fr = p.filter_radius;
+        const size_t lds = (size_t)(SW_TX + 2 * fr) * (SW_TY + 2 * fr) * C * sizeof(float);
+        dim3 grid((p.H + SW_TY - 1) / SW_TY, (p.W + SW_TX - 1) / SW_TX, p.E);
+        hipLaunchKernelGGL((k_sweep_tiled<C>), grid, dim3(256), lds, st, p, in, out);
+    }
+    return hipGetLastError();
+}
+
+hipError_t antsrl_launch_sweep(const KP &p, int cur, hipStream_t st)
+{
+    switch (p.C) {
+    case 1: return launch_sweep_c<1>(p, cur, st);
+    case 2: return launch_sweep_c<2>(p, cur, st);
+    case 3: return launch_sweep_c<3>(p, cur, st);
+    case 4: return launch_sweep_c<4>(p, cur, st);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t antsrl_launch_phero_wall_clear(const KP &p, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_phero_wall_clear, dim3(grid_for((size_t)p.E * p.W * p.H)), dim3(256), 0, st, p);
+    return hipGetLastError();
+}
+
+hipError_t antsrl_launch_phero_renorm(const KP &p, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_phero_renorm, dim3(grid_for((size_t)p.E * p.W * p.H * p.C)), dim3(256), 0, st, p);
+    return hipGetLastError();
+}

@@ -8,11 +8,11 @@ if [ "$1" = build ]; then
   mkdir -p $V; src=$R/antsrl_amd/csrc; inc=$R/include
   if [ -n "$3" ]; then
     tmp=$(mktemp -d); mkdir -p $tmp/antsrl_amd/csrc $tmp/include
-    for f in antsrl_kernels.hip antsrl_capi.hip antsrl_policy.hip antsrl_device.h; do git -C $R show $3:antsrl_amd/csrc/$f > $tmp/antsrl_amd/csrc/$f; done
+    for f in $(git -C $R ls-tree --name-only $3 antsrl_amd/csrc/); do git -C $R show $3:$f > $tmp/$f; done
     git -C $R show $3:include/antsrl.h > $tmp/include/antsrl.h; src=$tmp/antsrl_amd/csrc
   fi
   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared -std=c++17 -Wno-unused-function \
-    $src/antsrl_kernels.hip $src/antsrl_capi.hip $src/antsrl_policy.hip -o $V/$2.so && echo built $V/$2.so
+    $src/*.hip -o $V/$2.so && echo built $V/$2.so
   exit $?
 fi
 shift; A=$1; B=$2; N=${3:-3}; shift 3

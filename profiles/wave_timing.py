@@ -1,6 +1,6 @@
 """Per-wave time split of k_act's perception loop (instrumented build, not in the tree):
 
-    git apply profiles/wave_timing.patch && profiles/ab.sh build timing && git checkout antsrl_amd/csrc/antsrl_kernels.hip
+    git apply profiles/wave_timing.patch && profiles/ab.sh build timing && git checkout antsrl_amd/csrc/antsrl_act.hip
     gpurun -- 'ANTSRL_LIB=$GRAFT_REPO_ROOT/antsrl_amd/lib/variants/timing.so python3 profiles/wave_timing.py'
 
 The patch brackets the four parts of an iteration with s_memrealtime (100 MHz) and accumulates them per
