@@ -1,5 +1,8 @@
 #!/bin/bash
-# Profiling ablations of k_act (results invalid while ANTSRL_ABLATE is set): per-kernel ms from bench.py
+# Profiling ablations of k_act (results invalid while ANTSRL_ABLATE is set): per-kernel ms from bench.py.
+# NOTE: 256 (no perception), 512 (no gathers) and 1024 (no stores) select the GENERIC perception loop, not the
+# pipelined one the bench normally runs — compare them with each other, not with ablate=0; 2048 (no
+# explored-map marks) and 32768 (phase timeline) keep the pipelined loop.
 R=${GRAFT_REPO_ROOT:-/root/repo}
 for a in 0 256 512 1024 2048 1536 3584; do
   ANTSRL_ABLATE=$a python3 $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline ${BENCH_ARGS} 2>/dev/null | python3 -c "
