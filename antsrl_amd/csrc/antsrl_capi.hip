@@ -75,6 +75,8 @@ static int validate(const AntsCfg *c)
     if (c->n_envs < 1 || c->n_ants < 1 || c->w < 1 || c->h < 1)
         return fail(ANTSRL_E_INVALID, "n_envs, n_ants, w, h must be >= 1");
     if ((long long)c->w * c->h > (1ll << 30)) return fail(ANTSRL_E_INVALID, "grid too large");
+    if (c->n_envs > 65535) // the sweep / stencil kernels index envs with blockIdx.y
+        return fail(ANTSRL_E_INVALID, "n_envs must be <= 65535 per handle (shard larger batches over handles / GPUs)");
     if (c->n_phero < 1 || c->n_phero > ANTSRL_MAX_PHERO)
         return fail(ANTSRL_E_INVALID, "n_phero must be in 1..%d", ANTSRL_MAX_PHERO);
     if (c->n_rocks < 0 || c->n_rocks > 32) return fail(ANTSRL_E_INVALID, "n_rocks must be in 0..32");

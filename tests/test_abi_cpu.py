@@ -54,6 +54,9 @@ def test_workspace_bytes_and_validation(lib):
     bad.n_phero = 9
     assert lib.antsrl_workspace_bytes(C.byref(bad), C.byref(n)) == -1
     assert b"n_phero" in lib.antsrl_last_error()
+    big = make_cfg(70000, 4, 16, 16)
+    assert lib.antsrl_workspace_bytes(C.byref(big), C.byref(n)) == -1
+    assert b"65535" in lib.antsrl_last_error()
     bad = cfg.copy()
     bad.abi_version = 7
     assert lib.antsrl_workspace_bytes(C.byref(bad), C.byref(n)) == -1
