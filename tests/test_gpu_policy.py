@@ -77,3 +77,30 @@ def test_policy_on_bfloat16_observations_matches_float32_path():
         ra, pa = ra.clone(), pa.clone()
         rb, pb = pol.act(b.obs, b.agent_state, logits=lb, env=b)
         assert torch.equal(la, lb) and torch.equal(ra, rb) and torch.equal(pa, pb)
+
+
+@pytest.mark.parametrize("F", [4, 9, 62, 63, 64, 65, 66, 127, 128, 130, 343, 1000])
+def test_policy_feature_sizes_and_row_counts(F):
+    """Chunk boundaries of the streamed rows: feature counts around multiples of 64 (whole chunks, a
+    partial last chunk, the two agent_state inputs alone in the last chunk), row counts that are not a
+    multiple of the 32-ant tile, float32 and bfloat16 observations."""
+    import torch
+    from antsrl_amd import config as cm
+    from antsrl_amd.batched import BatchedAntsEnv
+    from antsrl_amd.policy import LinearPolicy
+    dev = torch.device("cuda")
+    henv = BatchedAntsEnv(cm.make_cfg(1, 4, 16, 16), obs_dtype=torch.bfloat16)  # only supplies the bf16 handle
+    pol = LinearPolicy(F, dev, seed=F)
+    g = torch.Generator(device=dev)
+    g.manual_seed(F)
+    for M in (1, 31, 33, 100):
+        obs = torch.rand((M, F), device=dev, generator=g) * 2 - 1
+        ast = torch.rand((M, 2), device=dev, generator=g) * 5
+        ref = pol.reference_logits(obs, ast)
+        l32 = torch.empty((M, 6), device=dev)
+        l16 = torch.empty((M, 6), device=dev)
+        r32, p32 = pol.act(obs.view(M, 1, 1, F), ast, logits=l32)
+        r32, p32 = r32.clone(), p32.clone()
+        r16, p16 = pol.act(obs.to(torch.bfloat16).view(M, 1, 1, F), ast, logits=l16, env=henv)
+        assert torch.allclose(l32, ref, rtol=0, atol=3e-3 * max(1.0, (F / 300) ** 0.5)), (F, M, float((l32 - ref).abs().max()))
+        assert torch.equal(l32, l16) and torch.equal(r32, r16) and torch.equal(p32, p16), (F, M)
