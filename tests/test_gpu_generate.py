@@ -102,3 +102,27 @@ def test_device_generator_behind_the_reference_surface():
         flags.append((d, env.timestep))
     # separate step()/update() calls do not auto-reset (only the fused antsrl_step_update does)
     assert [f[0] for f in flags] == [False, False, True, False] and flags[-1][1] == 5
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_generate_random_shapes_and_parameters(seed):
+    """The device generator against the oracle's restatement over random grid shapes, ant counts,
+    rock counts and generator parameters (including no food discs, dense walls, tiny grids)."""
+    from antsrl_amd import config as cm
+    from antsrl_amd.batched import BatchedAntsEnv
+    rng = np.random.default_rng(500 + seed)
+    E, N = int(rng.integers(1, 5)), int(rng.choice([1, 9, 64, 130, 300]))
+    W, H = int(rng.integers(16, 150)), int(rng.integers(16, 150))
+    cfg = cm.make_cfg(E, N, W, H, n_rocks=int(rng.integers(0, 5)), deposit_strength=256.0)
+    rmin = int(rng.integers(1, 6))
+    gen = cm.make_gen(wall_density=float(rng.choice([0.0, 0.05, 0.3])), n_food_discs=int(rng.choice([0, 1, 7, 20])),
+                      food_rmin=rmin, food_rmax=rmin + int(rng.integers(0, 6)))
+    env = BatchedAntsEnv(cfg)
+    env.generate(gen, episode_seed=1000 + seed)
+    orc = _check_fresh_episode(env, cfg, gen, 1000 + seed)
+    rot = rng.integers(-1, 2, (E, N), dtype=np.int8)
+    ph = rng.integers(0, 3, (E, N), dtype=np.int8)
+    obs, ast, rew, done = env.step_update(rot, ph)
+    o_obs, o_ast, o_rew, o_done = orc.step(rot, ph)
+    np.testing.assert_array_equal(_cpu(rew), o_rew.astype(np.float32))
+    np.testing.assert_array_equal(_cpu(obs)[..., [0, 3, 4, 5]], o_obs[..., [0, 3, 4, 5]])
