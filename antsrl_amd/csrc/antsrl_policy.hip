@@ -25,6 +25,7 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 struct __attribute__((packed, aligned(4))) F4 { float v[4]; }; // 4-byte aligned 16-byte load
 struct __attribute__((packed, aligned(4))) D3 { uint32_t v[3]; }; // 4-byte aligned 12-byte load
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) uint32_t stream4u;
 #define POL_KC 64                 // inputs per staged chunk (4 MFMA k-steps)
 #define POL_SROW (POL_KC + 8)     // bf16 per staged row: 144-byte stride = 16-byte aligned rows, 4-bank skew per row
 
@@ -282,12 +283,185 @@ k_policy_mlp(const float *__restrict__ obs, const float *__restrict__ agent_stat
     }
 }
 
+// ===================================================================================
+// k_policy_flat — the same network, with each 32-ant tile of the observation tensor streamed as ONE flat,
+// aligned, fully coalesced run (a tile's rows are contiguous: 32 * F elements) into a wave-private LDS
+// image in bf16; the MFMA B fragments (lane (r, h), k-step s = inputs 16 s + 8 h .. + 7 of ant r) are then
+// read from that image at whatever 2-byte alignment r * F gives them: five aligned dwords and a funnel
+// shift.  20 load instructions per tile instead of ~90 row-strided ones.  W1's columns for k >= F are
+// zero in LDS, so whatever follows a row in the image (the next row, the zeroed pad) contributes
+// nothing; the two agent_state inputs are a rank-2 update in registers on bf16-rounded operands.
+// Used whenever W1 + two tile images fit in LDS (any F the reference's perception can produce).
+// ===================================================================================
+template <bool OBS16>
+__global__ void __launch_bounds__(128)
+k_policy_flat(const float *__restrict__ obs, const float *__restrict__ agent_state, const float *__restrict__ w1,
+              const float *__restrict__ b1, const float *__restrict__ w2, const float *__restrict__ b2,
+              const float *__restrict__ w3, const float *__restrict__ b3, int8_t *__restrict__ rot_out,
+              int8_t *__restrict__ ph_out, float *__restrict__ logits_out, const int M, const int F,
+              const int ksteps /* ceil(F / 16) */, const int tile_elems /* LDS image size per wave, bf16 */)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    __bf16 *w1s = reinterpret_cast<__bf16 *>(smem); // [32][KP], KP = 16*ksteps + 8 (8 = bank skew)
+    const int KP = 16 * ksteps + 8;
+    const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5, wib = threadIdx.x >> 6;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+    const int IN = F + 2;
+    uint16_t *img = reinterpret_cast<uint16_t *>(w1s + POL_HIDDEN * KP) + (size_t)wib * tile_elems;
+    for (int k = lane; k < 16 * ksteps; k += 64) { // W1 -> bf16, observation columns only (a wave takes 16 rows)
+        float wv[POL_HIDDEN / 2];
+#pragma unroll
+        for (int j = 0; j < POL_HIDDEN / 2; ++j) wv[j] = w1[(size_t)(wib + 2 * j) * IN + min(k, F - 1)];
+#pragma unroll
+        for (int j = 0; j < POL_HIDDEN / 2; ++j) w1s[(wib + 2 * j) * KP + k] = (__bf16)(k < F ? wv[j] : 0.0f);
+    }
+    for (int i = lane; i < tile_elems / 8; i += 64) reinterpret_cast<uint4 *>(img)[i] = make_uint4(0, 0, 0, 0);
+    bf16x8 a2[2]; // heads, see k_policy_mlp
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int hid = 16 * s + 8 * (j >> 2) + 4 * h + (j & 3);
+            const float wa = w2[min(r, 2) * POL_HIDDEN + hid];
+            const float wb = w3 ? w3[min(max(r - 3, 0), 2) * POL_HIDDEN + hid] : 0.0f;
+            a2[s][j] = (__bf16)(r < 3 ? wa : (r < 6 ? wb : 0.0f));
+        }
+    float bias1[16], was0[16], was1[16];
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+        const int hid = (g & 3) + 8 * (g >> 2) + 4 * h;
+        bias1[g] = b1[hid];
+        was0[g] = (float)(__bf16)w1[(size_t)hid * IN + F];
+        was1[g] = (float)(__bf16)w1[(size_t)hid * IN + F + 1];
+    }
+    float hb[6];
+#pragma unroll
+    for (int o = 0; o < 6; ++o) hb[o] = o < 3 ? b2[o] : (w3 ? b3[o - 3] : 0.0f);
+    __syncthreads();
+
+    const int ntiles = (M + 31) / 32;
+    const __bf16 *wrow = w1s + r * KP + 8 * h;
+    for (int t = wave; t < ntiles; t += nwaves) {
+        const int ant = min(t * 32 + r, M - 1); // clamped: duplicates are not written back
+        const int rows = min(32, M - t * 32);
+        const uint32_t nelem = (uint32_t)rows * (uint32_t)F;
+        const float as0 = (float)(__bf16)agent_state[(size_t)ant * 2], as1 = (float)(__bf16)agent_state[(size_t)ant * 2 + 1];
+        pol_wave_sync(); // the previous tile's fragment reads are done
+        // ---- producer: the tile as a flat run of 16-byte pieces, 8 loads in flight per batch
+        if constexpr (OBS16) {
+            const uint16_t *src = reinterpret_cast<const uint16_t *>(obs) + (size_t)t * 32 * F; // 64-byte aligned
+            const uint32_t n16 = nelem >> 3; // whole 8-element pieces; the < 8 elements left over go one by one
+            for (uint32_t b0 = 0; b0 < n16; b0 += 8 * 64) {
+                uint4 v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = reinterpret_cast<const uint4 *>(src)[min(b0 + 64u * j + lane, n16 - 1)];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) reinterpret_cast<uint4 *>(img)[min(b0 + 64u * j + lane, n16 - 1)] = v[j];
+            }
+            const uint32_t rem = nelem & 7u, e0 = n16 << 3;
+            const uint16_t tail = src[min(e0 + (uint32_t)lane, nelem - 1)]; // unconditional, clamped
+            if ((uint32_t)lane < rem) img[e0 + lane] = tail;
+        } else {
+            const float *src = obs + (size_t)t * 32 * F; // 128-byte aligned
+            const uint32_t n4 = nelem >> 2;
+            for (uint32_t b0 = 0; b0 < n4; b0 += 8 * 64) {
+                float4 v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = reinterpret_cast<const float4 *>(src)[min(b0 + 64u * j + lane, n4 - 1)];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    bf16x4 pk;
+                    pk[0] = (__bf16)v[j].x; pk[1] = (__bf16)v[j].y; pk[2] = (__bf16)v[j].z; pk[3] = (__bf16)v[j].w;
+                    reinterpret_cast<bf16x4 *>(img)[min(b0 + 64u * j + lane, n4 - 1)] = pk;
+                }
+            }
+            const uint32_t rem = nelem & 3u, e0 = n4 << 2;
+            const float tail = src[min(e0 + (uint32_t)lane, nelem - 1)];
+            if ((uint32_t)lane < rem) img[e0 + lane] = __builtin_bit_cast(uint16_t, (__bf16)tail);
+        }
+        pol_wave_sync();
+        // ---- consumer
+        f32x16 acc;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) acc[g] = 0.0f;
+        const uint32_t off0 = (uint32_t)r * (uint32_t)F + 8u * h;
+        for (int s = 0; s < ksteps; ++s) {
+            const uint32_t off = off0 + 16u * s, sh = (off & 1u) * 16u;
+            const uint32_t *d = reinterpret_cast<const uint32_t *>(img) + (off >> 1);
+            const uint32_t d0 = d[0], d1 = d[1], d2 = d[2], d3 = d[3], d4 = d[4];
+            const stream4u packed = {__builtin_amdgcn_alignbit(d1, d0, sh), __builtin_amdgcn_alignbit(d2, d1, sh),
+                                     __builtin_amdgcn_alignbit(d3, d2, sh), __builtin_amdgcn_alignbit(d4, d3, sh)};
+            const bf16x8 bfrag = __builtin_bit_cast(bf16x8, packed);
+            const bf16x8 afrag = *reinterpret_cast<const bf16x8 *>(wrow + 16 * s);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag, acc, 0, 0, 0);
+        }
+        f32x16 acc2;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) acc2[g] = 0.0f;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            bf16x8 hfrag;
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                hfrag[j] = (__bf16)(acc[8 * s + j] + (as0 * was0[8 * s + j] + as1 * was1[8 * s + j]) + bias1[8 * s + j]);
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[s], hfrag, acc2, 0, 0, 0);
+        }
+        float lg[6];
+        lg[0] = acc2[0]; lg[1] = acc2[1]; lg[2] = acc2[2]; lg[3] = acc2[3];
+        lg[4] = __shfl(acc2[0], r + 32); lg[5] = __shfl(acc2[1], r + 32);
+#pragma unroll
+        for (int o = 0; o < 6; ++o) lg[o] += hb[o];
+        if (h == 0 && t * 32 + r < M) {
+            int ar = 0, ap = 0; // torch.max(...).indices: first maximum wins
+            if (lg[1] > lg[ar]) ar = 1;
+            if (lg[2] > lg[ar]) ar = 2;
+            if (lg[4] > lg[3 + ap]) ap = 1;
+            if (lg[5] > lg[3 + ap]) ap = 2;
+            rot_out[ant] = (int8_t)(ar - 1);
+            if (ph_out) ph_out[ant] = (int8_t)ap;
+            if (logits_out)
+#pragma unroll
+                for (int o = 0; o < 6; ++o) logits_out[(size_t)ant * 6 + o] = lg[o];
+        }
+    }
+}
+
 hipError_t antsrl_launch_policy(const float *obs, const float *agent_state, const float *w1, const float *b1,
                                 const float *w2, const float *b2, const float *w3, const float *b3, int8_t *rot,
                                 int8_t *ph, float *logits, int M, int F, hipStream_t st, bool obs_bf16)
 {
+    if (M < 1 || F < 1) return hipErrorInvalidValue;
+    {
+        // flat-stream form: W1 (observation columns) + two wave-private tile images (32 F elements + the
+        // read-ahead of the last k-step, zero padded) in LDS
+        static const bool off = getenv("ANTSRL_POLICY_CHUNKED") != nullptr; // A/B: the chunked kernel
+        const int ks = (F + 15) / 16, tile_elems = (32 * F + 32 + 7) / 8 * 8;
+        const size_t lds = (size_t)POL_HIDDEN * (16 * ks + 8) * 2 + 2 * (size_t)tile_elems * 2;
+        if (!off && ks <= POL_MAX_KSTEPS && lds <= 160 * 1024) {
+            const int ntiles = (M + 31) / 32;
+            int per_cu = (int)((160 * 1024) / lds);
+            per_cu = per_cu < 1 ? 1 : (per_cu > 8 ? 8 : per_cu);
+            int blocks = (ntiles + 1) / 2;
+            if (blocks > 256 * per_cu) blocks = 256 * per_cu;
+            hipError_t e = hipSuccess;
+            if (obs_bf16) {
+                static size_t attr = 0;
+                if (lds > attr) { e = hipFuncSetAttribute((const void *)k_policy_flat<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = lds; }
+                if (e != hipSuccess) return e;
+                hipLaunchKernelGGL(k_policy_flat<true>, dim3(blocks), dim3(128), lds, st, obs, agent_state, w1, b1, w2, b2, w3,
+                                   b3, rot, ph, logits, M, F, ks, tile_elems);
+            } else {
+                static size_t attr = 0;
+                if (lds > attr) { e = hipFuncSetAttribute((const void *)k_policy_flat<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = lds; }
+                if (e != hipSuccess) return e;
+                hipLaunchKernelGGL(k_policy_flat<false>, dim3(blocks), dim3(128), lds, st, obs, agent_state, w1, b1, w2, b2, w3,
+                                   b3, rot, ph, logits, M, F, ks, tile_elems);
+            }
+            return hipGetLastError();
+        }
+    }
     const int ksteps = (F + 2 + 15) / 16;
-    if (ksteps > POL_MAX_KSTEPS || M < 1 || F < 1) return hipErrorInvalidValue;
+    if (ksteps > POL_MAX_KSTEPS) return hipErrorInvalidValue;
     const int ntiles = (M + 31) / 32;
     int blocks = (ntiles + 3) / 4;
     const size_t lds = (size_t)POL_HIDDEN * (16 * ksteps + 8) * 2 + 4 * 32 * (size_t)POL_SROW * 2; // W1 + 4 wave tiles
