@@ -124,6 +124,8 @@ def main():
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
     ap.add_argument("--envs", type=int, default=0, help="override envs per GPU")
     ap.add_argument("--rocks", type=int, default=-1, help="override the number of circle obstacles (profiling)")
+    ap.add_argument("--diffuse", type=float, default=0.0,
+                    help="the reference's DIFFUSE_FACTOR (pheromone.py:5-10): 3x3 filter with this weight on the 8 neighbours")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--policy", default=None, choices=["random", "mlp"],
@@ -172,6 +174,10 @@ def main():
         ax = np.arange(-3, 4)
         g = np.exp(-(ax[:, None] ** 2 + ax[None, :] ** 2) / 4.5)
         extra["filt"] = g / g.sum() * (1 - 0.001)
+    if args.diffuse > 0:
+        f3 = np.ones((3, 3)) * args.diffuse
+        f3[1, 1] = 1 - 8 * args.diffuse
+        extra["filt"] = f3 * (1 - 0.001)  # DIFFUSE_FILTER, pheromone.py:8-10
     cfg = cm.make_cfg(E, W_["N"], W_["W"], W_["H"], **extra)
     policy_kind = args.policy or W_.get("policy", "random")
     obs_dtype = args.obs_dtype or ("bf16" if policy_kind == "mlp" else "f32")
