@@ -20,7 +20,8 @@
  *  - return value 0 = success, negative = error (see ANTSRL_E_*); nothing is
  *    thrown across the ABI; antsrl_last_error() gives a message for the last
  *    failure on the calling thread;
- *  - one handle per device; a handle is not thread-safe.
+ *  - a handle belongs to the device its workspace lives on (any number of handles per device), holds up
+ *    to 65535 environments and is not thread-safe.
  */
 #ifndef ANTSRL_H
 #define ANTSRL_H
