@@ -211,6 +211,30 @@ __global__ __launch_bounds__(512) void k_gather(const float2 *ph, const float *f
     if (acc == 12345.678f) sink[0] = acc;
 }
 
+// the same perception-shaped gathers from ONE interleaved array {p0, p1, food, pad} (16 bytes per cell): a
+// single 16-byte gather per ant instead of an 8-byte and a 4-byte one
+__global__ __launch_bounds__(512) void k_gather16(const float4 *grid, float *sink, int n, int hot)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t base = hot ? 0 : (size_t)blockIdx.x * 65536;
+    const int a = lane / 7 - 3, b = lane % 7 - 3;
+    float acc = 0.0f;
+    uint32_t rng = blockIdx.x * 977u + wave * 131u + 7u;
+    for (int i = 0; i < n; i += 2) {
+        float4 p[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            rng = rng * 1664525u + 1013904223u;
+            const int cx = (rng >> 8) & 255, cy = (rng >> 16) & 255;
+            const float th = (float)(rng & 255) * 0.0245f, ct = __cosf(th), st = __sinf(th);
+            const int ix = (cx + (int)rintf(1.1f * (ct * b - st * a))) & 255, iy = (cy + (int)rintf(1.1f * (st * b + ct * a))) & 255;
+            p[u] = grid[base + (uint32_t)(ix * 256 + iy)];
+        }
+        acc += p[0].x + p[0].y + p[0].z + p[1].x + p[1].y + p[1].z;
+    }
+    if (acc == 12345.678f) sink[0] = acc;
+}
+
 // grid-stride streaming fill over the whole tensor (what a memset-like kernel does)
 __global__ __launch_bounds__(256) void k_fill(float4 *out, size_t n4)
 {
@@ -301,6 +325,15 @@ int main(int argc, char **argv)
                 printf("gathers E=%4d %s: %.4f ms for 64 ants per wave = %.0f cycles per ant per CU (incl. address math)\n", e,
                        hot ? "L2-hot " : "per-env", t, per_ant_cycles);
             }
+        float4 *g16;
+        CK(hipMalloc(&g16, (size_t)1024 * 65536 * 16)); CK(hipMemset(g16, 0, (size_t)1024 * 65536 * 16));
+        for (int e : {256, 1024})
+            for (int hot : {1, 0}) {
+                const double t = time_ms([&] { k_gather16<<<e, 512>>>(g16, buf, 64, hot); }, 20);
+                printf("gathers (one 16-byte array) E=%4d %s: %.4f ms = %.0f cycles per ant per CU\n", e, hot ? "L2-hot " : "per-env", t,
+                       t * 1e-3 * 2.4e9 / ((e / 256.0) * 8 * 64));
+            }
+        CK(hipFree(g16));
         CK(hipFree(ph)); CK(hipFree(fd));
     }
     CK(hipFree(buf));
