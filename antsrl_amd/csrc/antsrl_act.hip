@@ -107,7 +107,7 @@ extern "C" int antsrl_debug_read_act_trace(unsigned long long *dst, int n_wg)
 // LDS carve (`ActLds`), its pointers go through scratch and every LDS access degrades to flat_*.
 // TPB = threads per workgroup (512 or 1024); 4 waves per SIMD (<= 128 VGPRs) is all the LDS plans
 // can use (capping at 80 VGPRs for a third workgroup per CU measured slower, see plan_act).
-template <int C, bool STATIC_LDS, int LAYOUT, bool FAST, int TPB, bool OBS16 = false>
+template <int C, bool STATIC_LDS, int LAYOUT, bool FAST, int TPB, bool OBS16 = false, bool ILV = false>
 __global__ void __launch_bounds__(TPB, 4)
 k_act(const KP p, const int8_t *__restrict__ rotation, const int8_t *__restrict__ phero_act, const int cur,
       float *__restrict__ obs, float *__restrict__ agent_state, float *__restrict__ reward,
@@ -142,8 +142,9 @@ k_act(const KP p, const int8_t *__restrict__ rotation, const int8_t *__restrict_
     uint32_t *g_expl = p.s.explored_bits + (size_t)e * p.words;
     const uint32_t *walls = STATIC_LDS ? L.b_walls : g_walls;
     const uint32_t *area = STATIC_LDS ? L.b_area : g_area;
-    float *food = p.s.food + (size_t)e * G;
-    const float *ph = p.s.phero[cur] + (size_t)e * G * C;
+    const FoodView food{p.s.food + (size_t)e * G * p.fs, p.fs};
+    const size_t PS = (size_t)p.ps; // floats per cell of the pheromone array (4 = interleaved record, see DState)
+    const float *ph = p.s.phero[cur] + (size_t)e * G * PS;
     const bool do_step = flags & ACT_STEP;
     const bool explore = p.explore_on != 0;
     const uint8_t primed0 = p.s.reward_primed[e];
@@ -386,13 +387,18 @@ k_act(const KP p, const int8_t *__restrict__ rotation, const int8_t *__restrict_
         _Pragma("unroll") for (int u = 0; u < ACT_UNROLL; ++u)                                           \
         {                                                                                                \
             const uint32_t gc_ = CELL[u];                                                                \
-            if (C == 2) {                                                                                \
-                const float2 t = *reinterpret_cast<const float2 *>(ph + (size_t)gc_ * 2);                \
-                PVV[u][0] = t.x; PVV[u][C - 1] = t.y;                                                    \
+            if (ILV) { /* one {p0, p1, food, pad} record per cell: a single 16-byte gather */            \
+                const float4 t = *reinterpret_cast<const float4 *>(ph + (size_t)gc_ * 4);                \
+                PVV[u][0] = t.x; PVV[u][C - 1] = t.y; FDV[u] = t.z;                                      \
             } else {                                                                                     \
-                _Pragma("unroll") for (int c = 0; c < C; ++c) PVV[u][c] = ph[(size_t)gc_ * C + c];       \
+                if (C == 2) {                                                                            \
+                    const float2 t = *reinterpret_cast<const float2 *>(ph + (size_t)gc_ * 2);            \
+                    PVV[u][0] = t.x; PVV[u][C - 1] = t.y;                                                \
+                } else {                                                                                 \
+                    _Pragma("unroll") for (int c = 0; c < C; ++c) PVV[u][c] = ph[(size_t)gc_ * C + c];   \
+                }                                                                                        \
+                FDV[u] = food[gc_];                                                                      \
             }                                                                                            \
-            FDV[u] = food[gc_];                                                                          \
         }                                                                                                \
     }
         uint32_t c_cell[ACT_UNROLL], n_cell[ACT_UNROLL];
@@ -565,11 +571,11 @@ k_act(const KP p, const int8_t *__restrict__ rotation, const int8_t *__restrict_
                 for (int c = 0; c < C; ++c) pv[u][c] = 0.0f;
                 if (vis[u] && !abl_gather) {
                     if (C == 2) {
-                        const float2 t = *reinterpret_cast<const float2 *>(ph + (size_t)cell[u] * 2);
+                        const float2 t = *reinterpret_cast<const float2 *>(ph + (size_t)cell[u] * PS);
                         pv[u][0] = t.x; pv[u][C - 1] = t.y;
                     } else {
 #pragma unroll
-                        for (int c = 0; c < C; ++c) pv[u][c] = ph[(size_t)cell[u] * C + c];
+                        for (int c = 0; c < C; ++c) pv[u][c] = ph[(size_t)cell[u] * PS + c];
                     }
                     fd[u] = food[cell[u]];
                 }
@@ -769,32 +775,32 @@ static int act_layout(const KP &p)
     return p.K == 6 ? LAYOUT_DEFAULT : LAYOUT_DEFAULT_ROCKS;
 }
 
-template <int C, bool ST, int LAYOUT, bool FAST, int TPB, bool OBS16 = false>
+template <int C, bool ST, int LAYOUT, bool FAST, int TPB, bool OBS16 = false, bool ILV = false>
 static hipError_t launch_act_t(const KP &p, const ActPlan &pl, const int8_t *rot, const int8_t *ph, int cur,
                                float *obs, float *agent_state, float *reward, uint8_t *done, int flags,
                                const double *jitter, int out_buf, hipStream_t st)
 {
     static size_t attr_lds = 0; // dynamic-LDS opt-in is per kernel function, set once per size
     if (pl.lds > attr_lds) {
-        hipError_t err = hipFuncSetAttribute((const void *)k_act<C, ST, LAYOUT, FAST, TPB, OBS16>,
+        hipError_t err = hipFuncSetAttribute((const void *)k_act<C, ST, LAYOUT, FAST, TPB, OBS16, ILV>,
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds);
         if (err != hipSuccess) return err;
         attr_lds = pl.lds;
     }
-    hipLaunchKernelGGL((k_act<C, ST, LAYOUT, FAST, TPB, OBS16>), dim3(p.E), dim3(TPB), pl.lds, st, p, rot, ph, cur, obs,
+    hipLaunchKernelGGL((k_act<C, ST, LAYOUT, FAST, TPB, OBS16, ILV>), dim3(p.E), dim3(TPB), pl.lds, st, p, rot, ph, cur, obs,
                        agent_state, reward, done, flags, jitter, out_buf);
     return hipGetLastError();
 }
 
-template <int C, bool ST, int LAYOUT, bool FAST, bool OBS16 = false>
+template <int C, bool ST, int LAYOUT, bool FAST, bool OBS16 = false, bool ILV = false>
 static hipError_t launch_act_k(const KP &p, const ActPlan &pl, const int8_t *rot, const int8_t *ph, int cur,
                                float *obs, float *agent_state, float *reward, uint8_t *done, int flags,
                                const double *jitter, int out_buf, hipStream_t st)
 {
     if (pl.threads == 1024)
-        return launch_act_t<C, ST, LAYOUT, FAST, 1024, OBS16>(p, pl, rot, ph, cur, obs, agent_state, reward, done, flags,
+        return launch_act_t<C, ST, LAYOUT, FAST, 1024, OBS16, ILV>(p, pl, rot, ph, cur, obs, agent_state, reward, done, flags,
                                                        jitter, out_buf, st);
-    return launch_act_t<C, ST, LAYOUT, FAST, 512, OBS16>(p, pl, rot, ph, cur, obs, agent_state, reward, done, flags, jitter,
+    return launch_act_t<C, ST, LAYOUT, FAST, 512, OBS16, ILV>(p, pl, rot, ph, cur, obs, agent_state, reward, done, flags, jitter,
                                                   out_buf, st);
 }
 
@@ -812,30 +818,32 @@ static hipError_t launch_act_c(const KP &p, const int8_t *rot, const int8_t *ph,
                       !(flags & 0x700); // (ACT_ABL_NO_EXPLORE is honoured by the pipelined loop too)
 #define ACT_GO(ST, LY, FA) \
     return launch_act_k<C, ST, LY, FA>(p, pl, rot, ph, cur, obs, agent_state, reward, done, flags, jitter, out_buf, st)
-#define ACT_GO16(ST, LY) \
-    return launch_act_k<C, ST, LY, true, true>(p, pl, rot, ph, cur, obs, agent_state, reward, done, flags, jitter, out_buf, st)
-    if (flags & ACT_OBS_BF16) { // bfloat16 observations: the pipelined loop on a default channel layout
-        if (!fast || C != 2) return hipErrorNotSupported;
-        if constexpr (C == 2) {
-            if (layout == LAYOUT_DEFAULT) { if (pl.static_lds) ACT_GO16(true, LAYOUT_DEFAULT); else ACT_GO16(false, LAYOUT_DEFAULT); }
-            else { if (pl.static_lds) ACT_GO16(true, LAYOUT_DEFAULT_ROCKS); else ACT_GO16(false, LAYOUT_DEFAULT_ROCKS); }
-        }
+#define ACT_GOF(ST, LY, O16, IL) \
+    return launch_act_k<C, ST, LY, true, O16, IL>(p, pl, rot, ph, cur, obs, agent_state, reward, done, flags, jitter, out_buf, st)
+    // the pipelined loop is specialised on the observation format and on the cell record (DState::phero)
+#define ACT_FAST(ST, LY)                                                                          \
+    {                                                                                             \
+        if (o16) { if (ilv) ACT_GOF(ST, LY, true, true); else ACT_GOF(ST, LY, true, false); }     \
+        else { if (ilv) ACT_GOF(ST, LY, false, true); else ACT_GOF(ST, LY, false, false); }       \
     }
-    if (C == 2 && layout != LAYOUT_GENERIC) {
-        constexpr int LD = C == 2 ? LAYOUT_DEFAULT : LAYOUT_GENERIC, LR = C == 2 ? LAYOUT_DEFAULT_ROCKS : LAYOUT_GENERIC;
-        constexpr bool F = C == 2;
-        if (layout == LAYOUT_DEFAULT) {
-            if (fast) { if (pl.static_lds) ACT_GO(true, LD, F); else ACT_GO(false, LD, F); }
-            if (pl.static_lds) ACT_GO(true, LD, false); else ACT_GO(false, LD, false);
-        } else {
-            if (fast) { if (pl.static_lds) ACT_GO(true, LR, F); else ACT_GO(false, LR, F); }
-            if (pl.static_lds) ACT_GO(true, LR, false); else ACT_GO(false, LR, false);
+    const bool o16 = (flags & ACT_OBS_BF16) != 0, ilv = p.ps == 4 && p.fs == 4;
+    if (o16 && (!fast || C != 2)) return hipErrorNotSupported; // bfloat16 observations: pipelined loop only
+    if constexpr (C == 2) {
+        if (layout != LAYOUT_GENERIC) {
+            if (layout == LAYOUT_DEFAULT) {
+                if (fast) { if (pl.static_lds) ACT_FAST(true, LAYOUT_DEFAULT) else ACT_FAST(false, LAYOUT_DEFAULT) }
+                if (pl.static_lds) ACT_GO(true, LAYOUT_DEFAULT, false); else ACT_GO(false, LAYOUT_DEFAULT, false);
+            } else {
+                if (fast) { if (pl.static_lds) ACT_FAST(true, LAYOUT_DEFAULT_ROCKS) else ACT_FAST(false, LAYOUT_DEFAULT_ROCKS) }
+                if (pl.static_lds) ACT_GO(true, LAYOUT_DEFAULT_ROCKS, false); else ACT_GO(false, LAYOUT_DEFAULT_ROCKS, false);
+            }
         }
     }
     if (pl.static_lds) ACT_GO(true, LAYOUT_GENERIC, false);
     ACT_GO(false, LAYOUT_GENERIC, false);
 #undef ACT_GO
-#undef ACT_GO16
+#undef ACT_GOF
+#undef ACT_FAST
 }
 
 hipError_t antsrl_launch_act(const KP &p, const int8_t *rot, const int8_t *ph, int cur, float *obs,

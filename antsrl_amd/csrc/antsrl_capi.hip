@@ -110,6 +110,16 @@ static bool use_scaled(const AntsCfg *c)
            c->filter[0] <= 1.0 && c->phero_threshold >= 0.0;
 }
 
+// Interleaved cell record {p0, p1, food, pad}: with scaled units there is no per-step sweep whose traffic the
+// wider record would inflate, and a perception becomes ONE 16-byte gather per cell instead of an 8-byte
+// and a 4-byte one (profiles/obs_write_probe.hip: 48-57 cycles per ant per CU against 70-77 on L2 hits,
+// 180-197 against 275 from HBM).  ANTSRL_NO_INTERLEAVE keeps the separate arrays (A/B).
+static bool use_interleaved(const AntsCfg *c)
+{
+    static const bool off = getenv("ANTSRL_NO_INTERLEAVE") != nullptr;
+    return !off && use_scaled(c) && c->n_phero == 2;
+}
+
 // Carves the workspace; with base == NULL only computes the size.
 static size_t carve(const AntsCfg *c, DState *s, unsigned char *base)
 {
@@ -131,9 +141,14 @@ static size_t carve(const AntsCfg *c, DState *s, unsigned char *base)
     d.mandibles = (uint8_t *)take(E * N); d.reward_state = (uint8_t *)take(E * N);
     d.dirty_cell = (int32_t *)take(4 * E * N);
     d.walldep_cell = (int32_t *)take(4 * E * N);
-    d.phero[0] = (float *)take(4 * E * G * Cn);
-    d.phero[1] = use_scaled(c) ? d.phero[0] : (float *)take(4 * E * G * Cn); // no ping-pong when scaled
-    d.food = (float *)take(4 * E * G);
+    if (use_interleaved(c)) { // one {p0, p1, food, pad} record per cell
+        d.phero[0] = d.phero[1] = (float *)take(16 * E * G);
+        d.food = d.phero[0] ? d.phero[0] + 2 : nullptr;
+    } else {
+        d.phero[0] = (float *)take(4 * E * G * Cn);
+        d.phero[1] = use_scaled(c) ? d.phero[0] : (float *)take(4 * E * G * Cn); // no ping-pong when scaled
+        d.food = (float *)take(4 * E * G);
+    }
     d.walls_bits = (uint32_t *)take(4 * E * words); d.area_bits = (uint32_t *)take(4 * E * words);
     d.explored_bits = (uint32_t *)take(4 * E * words);
     d.anthill_xyr = (int32_t *)take(4 * E * 3);
@@ -216,6 +231,8 @@ static void fill_kp(const AntsCfg *c, KP *p)
     }
     p->rng_seed = c->rng_seed;
     p->scaled = use_scaled(c) ? 1 : 0;
+    p->ps = use_interleaved(c) ? 4 : c->n_phero;
+    p->fs = use_interleaved(c) ? 4 : 1;
     p->g_now = p->g_dep = p->inv_g_dep = 1.0;
 }
 

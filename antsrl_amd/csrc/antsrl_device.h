@@ -8,6 +8,9 @@
 //               (ping-pong: the decay/diffuse sweep reads `cur`, writes `cur^1`, then the
 //               deposit lands in `cur^1`).  One 8-byte gather returns both channels of a cell.
 //   food        f32 [E][W][H]
+//               With scaled pheromone units and two channels (the reference's setup: no per-step
+//               sweep) the two grids are ONE array of 16-byte cell records {p0, p1, food, pad}:
+//               a perception is then a single 16-byte gather per cell (KP::ps, KP::fs).
 //   walls / anthill area / explored map   bit-packed, 1 bit per cell: u32 [E][ceil(W*H/32)],
 //               bit index = x*H + y.  8 KiB per env at 256x256, so whole maps fit in LDS.
 //   rocks       float64 SoA [E][R]
@@ -25,8 +28,13 @@ struct DState {
                                              //        rewrote in the last step, else -1
     int32_t *walldep_cell;                   // [E*N]  (scaled mode) wall cell this ant deposited
                                              //        on in the last update, else -1
-    float *phero[2];                         // [E*G*C] each
-    float *food;                             // [E*G]
+    float *phero[2];                         // [E*G*ps] each: value of channel c of cell g at [g*ps + c]
+    float *food;                             // [E*G*fs]:  food of cell g at [g*fs]
+                                             // (KP::ps, KP::fs: cell strides in floats.  Separate arrays:
+                                             //  ps = C, fs = 1.  Interleaved record, scaled units with two
+                                             //  channels: ONE array of {p0, p1, food, pad} per cell, ps = fs
+                                             //  = 4, food = phero[0] + 2 — a perception is then a single
+                                             //  16-byte gather per cell)
     uint32_t *walls_bits, *area_bits, *explored_bits; // [E*words]
     int32_t *anthill_xyr;                    // [E*3]
     double *anthill_food;                    // [E]
@@ -53,6 +61,7 @@ struct KP {
     // Scaled pheromone representation (ANTSRL_PHERO_AUTO with a centre-only filter): the grid
     // holds u = v / f0^S_at_write; v_now = u * g_now with g = f0^S.  g == 1 in explicit mode.
     int32_t scaled, _pad;
+    int32_t ps, fs;   // cell strides of the pheromone / food arrays, see DState
     double g_now;     // f0^S          : materialises values for the perception gather / read-out
     double g_dep;     // f0^(S+1)      : at deposit time, after the conceptual sweep of this update
     double inv_g_dep; // 1 / g_dep

@@ -69,11 +69,11 @@ __global__ void k_reset_grids(const KP p, const float *__restrict__ food, const 
     const size_t G = (size_t)p.W * p.H, n = (size_t)p.E * G;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const size_t e = i / G, g = i - e * G;
-        p.s.food[i] = food[i];
+        p.s.food[i * p.fs] = food[i];
         for (int c = 0; c < p.C; ++c) {
             const float v = phero ? phero[(e * p.C + c) * G + g] : 0.0f;
-            p.s.phero[0][i * p.C + c] = v;
-            p.s.phero[1][i * p.C + c] = v;
+            p.s.phero[0][i * p.ps + c] = v;
+            p.s.phero[1][i * p.ps + c] = v;
         }
     }
 }
@@ -141,10 +141,10 @@ __global__ void k_gen_cells(const KP p, const AntsGen g, const uint64_t seed)
             }
             if (area) ab |= 1u << b;
             if (wall) wb |= 1u << b;
-            p.s.food[e * G + cell] = (fd && !wall) ? 1.0f : 0.0f;
+            p.s.food[(e * G + cell) * p.fs] = (fd && !wall) ? 1.0f : 0.0f;
             for (int c = 0; c < p.C; ++c) {
-                p.s.phero[0][(e * G + cell) * p.C + c] = 0.0f;
-                p.s.phero[1][(e * G + cell) * p.C + c] = 0.0f;
+                p.s.phero[0][(e * G + cell) * p.ps + c] = 0.0f;
+                p.s.phero[1][(e * G + cell) * p.ps + c] = 0.0f;
             }
         }
         p.s.walls_bits[i] = wb;
@@ -213,7 +213,7 @@ __global__ void k_read_state(const KP p, const int which, const int cur, void *_
     case ANTSRL_S_PHERO: // interleaved [E][G][C] -> canonical [E][C][G]
         for (size_t i = t0; i < EG * p.C; i += stride) {
             const size_t e = i / (G * p.C), rem = i - e * G * p.C, c = rem / G, g = rem - c * G;
-            float v = p.s.phero[cur][(e * G + g) * p.C + c];
+            float v = p.s.phero[cur][(e * G + g) * p.ps + c];
             if (p.scaled) {
                 v *= (float)p.g_now;
                 if (v < (float)p.threshold) v = 0.0f;
@@ -221,7 +221,7 @@ __global__ void k_read_state(const KP p, const int which, const int cur, void *_
             ((float *)dstv)[i] = v;
         }
         break;
-    case ANTSRL_S_FOOD: for (size_t i = t0; i < EG; i += stride) ((float *)dstv)[i] = p.s.food[i]; break;
+    case ANTSRL_S_FOOD: for (size_t i = t0; i < EG; i += stride) ((float *)dstv)[i] = p.s.food[i * p.fs]; break;
     case ANTSRL_S_EXPLORED:
     case ANTSRL_S_WALLS:
     case ANTSRL_S_ANTHILL_AREA: {

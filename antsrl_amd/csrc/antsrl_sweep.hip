@@ -133,7 +133,7 @@ __global__ void __launch_bounds__(256) k_phero_wall_clear(const KP p)
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const size_t e = i / G, g = i - e * G;
         if (test_bit(p.s.walls_bits + e * p.words, (uint32_t)g))
-            for (int c = 0; c < p.C; ++c) p.s.phero[0][i * p.C + c] = 0.0f;
+            for (int c = 0; c < p.C; ++c) p.s.phero[0][i * p.ps + c] = 0.0f;
     }
 }
 
@@ -142,8 +142,9 @@ __global__ void __launch_bounds__(256) k_phero_renorm(const KP p)
     // u := materialised value (units of f0^0); the host then restarts S at 0.
     const size_t n = (size_t)p.E * p.W * p.H * p.C;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const double v = (double)p.s.phero[0][i] * p.g_now;
-        p.s.phero[0][i] = v < p.threshold ? 0.0f : (float)v;
+        const size_t j = (i / p.C) * p.ps + (i % p.C); // (cell, channel) -> position under the cell stride
+        const double v = (double)p.s.phero[0][j] * p.g_now;
+        p.s.phero[0][j] = v < p.threshold ? 0.0f : (float)v;
     }
 }
 

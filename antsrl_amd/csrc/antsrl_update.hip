@@ -42,8 +42,9 @@ k_update_one(const KP p, const double *__restrict__ wall_jitter, const int out_b
     double *sx = (double *)((unsigned char *)wave_tot + align_up(4 * (size_t)nwaves, 8)), *sy = sx + N;
 
     const uint32_t *walls = p.s.walls_bits + (size_t)e * p.words;
-    float *food = p.s.food + (size_t)e * G;
-    float *out = p.s.phero[out_buf] + (size_t)e * G * C;
+    const FoodView food{p.s.food + (size_t)e * G * p.fs, p.fs};
+    const size_t PS = (size_t)p.ps; // floats per cell of the pheromone array
+    float *out = p.s.phero[out_buf] + (size_t)e * G * PS;
     const bool on = tid < N;
     const size_t a = eN + (on ? tid : 0);
 
@@ -170,7 +171,7 @@ k_update_one(const KP p, const double *__restrict__ wall_jitter, const int out_b
         // a deposit that landed on a WALL cell in the previous update is zeroed by this update's Walls
         // pass (walls.py:30), before this update's deposits
         if (wc >= 0) {
-            for (int c = 0; c < C; ++c) out[(size_t)wc * C + c] = 0.0f;
+            for (int c = 0; c < C; ++c) out[(size_t)wc * PS + c] = 0.0f;
             p.s.walldep_cell[a] = -1;
         }
         __syncthreads();
@@ -182,9 +183,9 @@ k_update_one(const KP p, const double *__restrict__ wall_jitter, const int out_b
 #pragma unroll
                 for (int c = 0; c < C; ++c) {
                     if (act[c] != 0.0f) {
-                        float v = out[(size_t)cell * C + c] + act[c];
+                        float v = out[(size_t)cell * PS + c] + act[c];
                         if (p.has_max_val) v = fminf(v, (float)p.max_val);
-                        out[(size_t)cell * C + c] = v;
+                        out[(size_t)cell * PS + c] = v;
                     }
                 }
             } else { // scaled units, see update_env
@@ -193,14 +194,14 @@ k_update_one(const KP p, const double *__restrict__ wall_jitter, const int out_b
 #pragma unroll
                 for (int c = 0; c < C; ++c) {
                     if (act[c] != 0.0f) {
-                        double v = (double)out[(size_t)cell * C + c] * p.g_dep;
+                        double v = (double)out[(size_t)cell * PS + c] * p.g_dep;
                         if (v < p.threshold || on_wall) v = 0.0;
                         v += (double)act[c];
                         if (p.has_max_val) v = fmin(v, p.max_val);
-                        out[(size_t)cell * C + c] = (float)(v * p.inv_g_dep);
+                        out[(size_t)cell * PS + c] = (float)(v * p.inv_g_dep);
                         wrote = true;
                     } else if (on_wall) {
-                        out[(size_t)cell * C + c] = 0.0f;
+                        out[(size_t)cell * PS + c] = 0.0f;
                     }
                 }
                 if (on_wall && wrote) p.s.walldep_cell[a] = (int32_t)cell;
@@ -231,7 +232,7 @@ __global__ void __launch_bounds__(256) k_collect_full(const KP p)
     __shared__ double red[4];
     const int e = blockIdx.x, tid = threadIdx.x;
     const size_t G = (size_t)p.W * p.H;
-    float *food = p.s.food + (size_t)e * G;
+    const FoodView food{p.s.food + (size_t)e * G * p.fs, p.fs};
     const uint32_t *area = p.s.area_bits + (size_t)e * p.words;
     double gain = 0.0;
     for (size_t g = tid; g < G; g += blockDim.x)

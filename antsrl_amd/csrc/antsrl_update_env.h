@@ -43,8 +43,9 @@ __device__ __forceinline__ void update_env(const KP &p, const int e, const doubl
     uint32_t *wave_tot = (uint32_t *)(red + nwaves);                 // [nwaves]
 
     const uint32_t *walls = p.s.walls_bits + (size_t)e * p.words;
-    float *food = p.s.food + (size_t)e * G;
-    float *out = p.s.phero[out_buf] + (size_t)e * G * C;
+    const FoodView food{p.s.food + (size_t)e * G * p.fs, p.fs};
+    const size_t PS = (size_t)p.ps; // floats per cell of the pheromone array
+    float *out = p.s.phero[out_buf] + (size_t)e * G * PS;
     const int ts = p.s.timestep[e] + 1; // environment.py:45
 
     for (int h = tid; h < p.HT; h += T) {
@@ -157,7 +158,7 @@ __device__ __forceinline__ void update_env(const KP &p, const int e, const doubl
         for (int i = tid; i < N; i += T) {
             const int32_t wc = p.s.walldep_cell[eN + i];
             if (wc >= 0) {
-                for (int c = 0; c < C; ++c) out[(size_t)wc * C + c] = 0.0f;
+                for (int c = 0; c < C; ++c) out[(size_t)wc * PS + c] = 0.0f;
                 p.s.walldep_cell[eN + i] = -1;
             }
         }
@@ -171,9 +172,9 @@ __device__ __forceinline__ void update_env(const KP &p, const int e, const doubl
                 for (int c = 0; c < C; ++c) {
                     const float a = p.s.activation[(eN + i) * C + c];
                     if (a != 0.0f) {
-                        float v = out[(size_t)cell * C + c] + a;
+                        float v = out[(size_t)cell * PS + c] + a;
                         if (p.has_max_val) v = fminf(v, (float)p.max_val);
-                        out[(size_t)cell * C + c] = v;
+                        out[(size_t)cell * PS + c] = v;
                     }
                 }
             } else {
@@ -186,14 +187,14 @@ __device__ __forceinline__ void update_env(const KP &p, const int e, const doubl
                 for (int c = 0; c < C; ++c) {
                     const float a = p.s.activation[(eN + i) * C + c];
                     if (a != 0.0f) {
-                        double v = (double)out[(size_t)cell * C + c] * p.g_dep;
+                        double v = (double)out[(size_t)cell * PS + c] * p.g_dep;
                         if (v < p.threshold || on_wall) v = 0.0;
                         v += (double)a;
                         if (p.has_max_val) v = fmin(v, p.max_val);
-                        out[(size_t)cell * C + c] = (float)(v * p.inv_g_dep);
+                        out[(size_t)cell * PS + c] = (float)(v * p.inv_g_dep);
                         wrote = true;
                     } else if (on_wall) {
-                        out[(size_t)cell * C + c] = 0.0f;
+                        out[(size_t)cell * PS + c] = 0.0f;
                     }
                 }
                 if (on_wall && wrote) p.s.walldep_cell[eN + i] = (int32_t)cell;

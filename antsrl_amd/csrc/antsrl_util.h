@@ -11,6 +11,13 @@
 #define PI_D 3.141592653589793
 #define HASH_EMPTY 0xFFFFFFFFu
 
+// food of cell g of one env, whatever the cell stride (DState::food): `food[g]` reads / writes it
+struct FoodView {
+    float *b;
+    int st;
+    __device__ __forceinline__ float &operator[](size_t g) const { return b[g * (size_t)st]; }
+};
+
 // ------------------------------------------------------------------ small helpers
 __device__ __forceinline__ double np_mod_d(double a, double b)
 {
