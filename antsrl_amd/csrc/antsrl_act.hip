@@ -509,7 +509,12 @@ k_act(const KP p, const int8_t *__restrict__ rotation, const int8_t *__restrict_
                 }
                 float *dst_al = dst - mis;
                 const uint32_t j_lo = (mis + 3) >> 2, j_hi = (mis + row) >> 2; // interior float4s [j_lo, j_hi)
-                const uint32_t ja = min(j_lo + (uint32_t)lane, j_hi - 1), jb = min(j_lo + 64u + (uint32_t)lane, j_hi - 1);
+                // store A covers 64 float4s that start on a 128-byte line (8 whole lines in one instruction:
+                // streaming stores of whole lines are cheaper than pieces, profiles/store_policy_probe.hip),
+                // store B the pieces in front of and behind them
+                const uint32_t head = (j_hi - j_lo >= 72u) ? ((8u - (((uint32_t)((uintptr_t)dst_al >> 4) + j_lo) & 7u)) & 7u) : 0u;
+                const uint32_t ja = min(j_lo + head + (uint32_t)lane, j_hi - 1);
+                const uint32_t jb = min((uint32_t)lane < head ? j_lo + (uint32_t)lane : j_lo + 64u + (uint32_t)lane, j_hi - 1);
                 const float4 va = reinterpret_cast<const float4 *>(stage)[ja];
                 const float4 vb = reinterpret_cast<const float4 *>(stage)[jb];
                 const uint32_t hd = 4 * j_lo - mis, tl = mis + row - 4 * j_hi;
