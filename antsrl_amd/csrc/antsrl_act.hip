@@ -56,7 +56,10 @@ __host__ __device__ __forceinline__ ActOff act_offsets(int N, int PP, int words,
     }
     o.mask = take((size_t)PP);
     o.rock = take(32 * (size_t)(R > 0 ? R : 1));
-    const size_t stride = ((size_t)PP * K + 3 + 3) / 4 * 4; // row + up to 3 floats of misalignment
+    // staging: one row + up to 3 floats of misalignment; TWO rows for the shapes the pipelined loop takes
+    // (it stages a group's rows back to back)
+    const size_t rowf = (size_t)PP * K;
+    const size_t stride = ((PP <= 64 && rowf <= 368 ? 2 * rowf : rowf) + 3 + 3) / 4 * 4;
     const size_t hash_b = update_scratch_bytes(HT, R, nwaves), stage_b = 4 * (size_t)nwaves * stride;
     o.uni = take(hash_b > stage_b ? hash_b : stage_b);
     o.stride = (uint32_t)stride;
@@ -349,14 +352,14 @@ k_act(const KP p, const int8_t *__restrict__ rotation, const int8_t *__restrict_
     const bool wrap_fast = W > 4 * (p.r + 4) && H > 4 * (p.r + 4) && p.fwd_delta < W / 4 && p.fwd_delta < H / 4 &&
                            p.fwd_delta > -W / 4 && p.fwd_delta > -H / 4 && p.delta < 2.0; // one conditional add wraps
     const bool wrap_pow2 = (W & (W - 1)) == 0 && (H & (H - 1)) == 0;
-    // Fast path (single pass: PP <= 64, row <= 508 floats — the reference's 7x7 with up to 10
+    // Fast path (single pass: PP <= 64, row <= 368 floats — the reference's 7x7 with its 6 or 7
     // channels): software-pipelined by one group of ACT_UNROLL ants.  Everything that touches
     // global memory is STRAIGHT-LINE and unconditional (out-of-range ants/lanes are clamped onto
     // valid ones and redo identical work: benign duplicate stores), so the compiler can count
     // outstanding operations: the wait for group g's gathers is a `vmcnt(n)` that leaves group
     // g+1's gathers AND group g-1's observation stores in flight.  (vmcnt retires in order and
     // counts stores: an uncounted wait would make every gather wait for the previous stores.)
-    if (FAST) { // host guarantees: npass == 1, 8 <= row <= 508, obs != nullptr
+    if (FAST) { // host guarantees: npass == 1, 8 <= row <= 368, obs != nullptr
         const int q = lane < PP ? lane : PP - 1;            // lanes beyond the perception clamp onto its last cell
         const CellOff of = L.off[q];
         const bool mask_q = L.t_mask[q] != 0;
@@ -434,9 +437,10 @@ k_act(const KP p, const int8_t *__restrict__ rotation, const int8_t *__restrict_
                     }
                     pvs[c] = v * inv_max; // :124-125, reciprocal multiply (pheromone channels are held to 1e-5)
                 }
-                float *dst = obs_env + (size_t)i * row;
-                const uint32_t mis = (uint32_t)(((uintptr_t)dst >> 2) & 3);
-                float *o = stage + mis + qK;
+                // float32: the group's rows are staged back to back, as they lie in memory (image shifted by
+                // the first row's 16-byte misalignment), and flushed together after the loop
+                const uint32_t mis0 = (uint32_t)(((uintptr_t)(obs_env + (size_t)i0 * row) >> 2) & 3);
+                float *o = stage + mis0 + (uint32_t)u * row + qK;
                 // bfloat16 observations: the same staging and copy-out on 2-byte elements (8 per 16 bytes)
                 uint16_t *dst16 = reinterpret_cast<uint16_t *>(obs) + ((size_t)e * N + (size_t)i) * row;
                 const uint32_t mis16 = (uint32_t)(((uintptr_t)dst16 >> 1) & 7);
@@ -487,11 +491,8 @@ k_act(const KP p, const int8_t *__restrict__ rotation, const int8_t *__restrict_
                         o[k] = m ? v : -1.0f;
                     }
                 }
-                wave_lds_sync();
-                // copy the row out: two 16-byte stores per lane over the fully-inside float4s of the
-                // aligned window [mis, mis+row), one 4-byte store for the <= 6 edge floats; lanes
-                // with nothing left repeat a valid store (same address, same data)
-                if (OBS16) {
+                if (OBS16) { // bfloat16 rows are copied out one by one
+                    wave_lds_sync();
                     // one 16-byte store per lane over the whole 8-element groups of the aligned window
                     // [mis16, mis16 + row) (<= 60 groups), one 2-byte store for the <= 14 edge elements
                     uint16_t *st16 = reinterpret_cast<uint16_t *>(stage), *d_al = dst16 - mis16;
@@ -507,22 +508,33 @@ k_act(const KP p, const int8_t *__restrict__ rotation, const int8_t *__restrict_
                     wave_lds_sync();
                     continue;
                 }
+            }
+            if (!OBS16) {
+                // copy the group out: its rows are contiguous in memory, so the (up to) two rows leave as ONE
+                // run: two 16-byte stores per lane over 128 float4s that start on a 128-byte line (16 whole
+                // lines: streaming stores of whole lines are cheaper than pieces,
+                // profiles/store_policy_probe.hip), a third over the pieces in front of and behind them,
+                // one 4-byte store for the <= 6 edge floats; lanes with nothing left repeat a valid store
+                wave_lds_sync();
+                const uint32_t rowp = (i0 + 1 < i_end) ? 2u * row : row; // (odd tail of the run: one row)
+                float *dst = obs_env + (size_t)i0 * row;
+                const uint32_t mis = (uint32_t)(((uintptr_t)dst >> 2) & 3);
                 float *dst_al = dst - mis;
-                const uint32_t j_lo = (mis + 3) >> 2, j_hi = (mis + row) >> 2; // interior float4s [j_lo, j_hi)
-                // store A covers 64 float4s that start on a 128-byte line (8 whole lines in one instruction:
-                // streaming stores of whole lines are cheaper than pieces, profiles/store_policy_probe.hip),
-                // store B the pieces in front of and behind them
+                const uint32_t j_lo = (mis + 3) >> 2, j_hi = (mis + rowp) >> 2; // interior float4s [j_lo, j_hi)
                 const uint32_t head = (j_hi - j_lo >= 72u) ? ((8u - (((uint32_t)((uintptr_t)dst_al >> 4) + j_lo) & 7u)) & 7u) : 0u;
-                const uint32_t ja = min(j_lo + head + (uint32_t)lane, j_hi - 1);
-                const uint32_t jb = min((uint32_t)lane < head ? j_lo + (uint32_t)lane : j_lo + 64u + (uint32_t)lane, j_hi - 1);
-                const float4 va = reinterpret_cast<const float4 *>(stage)[ja];
-                const float4 vb = reinterpret_cast<const float4 *>(stage)[jb];
-                const uint32_t hd = 4 * j_lo - mis, tl = mis + row - 4 * j_hi;
+                const uint32_t j1 = min(j_lo + head + (uint32_t)lane, j_hi - 1);
+                const uint32_t j2 = min(j_lo + head + 64u + (uint32_t)lane, j_hi - 1);
+                const uint32_t j3 = min((uint32_t)lane < head ? j_lo + (uint32_t)lane : j_lo + 128u + (uint32_t)lane, j_hi - 1);
+                const float4 v1 = reinterpret_cast<const float4 *>(stage)[j1];
+                const float4 v2 = reinterpret_cast<const float4 *>(stage)[j2];
+                const float4 v3 = reinterpret_cast<const float4 *>(stage)[j3];
+                const uint32_t hd = 4 * j_lo - mis, tl = mis + rowp - 4 * j_hi;
                 const uint32_t fe = (uint32_t)lane < hd ? mis + lane
                                     : ((uint32_t)lane - hd < tl ? 4 * j_hi + ((uint32_t)lane - hd) : mis);
                 const float ve = stage[fe];
-                store_stream(reinterpret_cast<float4 *>(dst_al) + ja, va);
-                store_stream(reinterpret_cast<float4 *>(dst_al) + jb, vb);
+                store_stream(reinterpret_cast<float4 *>(dst_al) + j1, v1);
+                store_stream(reinterpret_cast<float4 *>(dst_al) + j2, v2);
+                store_stream(reinterpret_cast<float4 *>(dst_al) + j3, v3);
                 store_stream(dst_al + fe, ve);
                 wave_lds_sync();
             }
@@ -818,8 +830,9 @@ static hipError_t launch_act_c(const KP &p, const int8_t *rot, const int8_t *ph,
     if (pl.lds > 160 * 1024) return hipErrorInvalidValue;
     const int layout = (C == 2) ? act_layout(p) : LAYOUT_GENERIC;
     const uint32_t row = (uint32_t)p.PP * p.K;
-    // the pipelined loop: one pass (PP <= 64), row of 8..508 floats, observation wanted, no ablation
-    const bool fast = C == 2 && layout != LAYOUT_GENERIC && p.PP <= 64 && row >= 8 && row <= 508 && obs &&
+    // the pipelined loop: one pass (PP <= 64), row of 8..368 floats (a group of two rows leaves in three
+    // 16-byte stores per lane), observation wanted, no ablation
+    const bool fast = C == 2 && layout != LAYOUT_GENERIC && p.PP <= 64 && row >= 8 && row <= 368 && obs &&
                       !(flags & 0x700); // (ACT_ABL_NO_EXPLORE is honoured by the pipelined loop too)
 #define ACT_GO(ST, LY, FA) \
     return launch_act_k<C, ST, LY, FA>(p, pl, rot, ph, cur, obs, agent_state, reward, done, flags, jitter, out_buf, st)
