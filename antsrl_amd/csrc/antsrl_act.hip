@@ -442,9 +442,9 @@ k_act(const KP p, const int8_t *__restrict__ rotation, const int8_t *__restrict_
                 const uint32_t mis0 = (uint32_t)(((uintptr_t)(obs_env + (size_t)i0 * row) >> 2) & 3);
                 float *o = stage + mis0 + (uint32_t)u * row + qK;
                 // bfloat16 observations: the same staging and copy-out on 2-byte elements (8 per 16 bytes)
-                uint16_t *dst16 = reinterpret_cast<uint16_t *>(obs) + ((size_t)e * N + (size_t)i) * row;
-                const uint32_t mis16 = (uint32_t)(((uintptr_t)dst16 >> 1) & 7);
-                uint16_t *o16 = reinterpret_cast<uint16_t *>(stage) + mis16 + qK;
+                uint16_t *dst16_0 = reinterpret_cast<uint16_t *>(obs) + ((size_t)e * N + (size_t)i0) * row;
+                const uint32_t mis16_0 = (uint32_t)(((uintptr_t)dst16_0 >> 1) & 7);
+                uint16_t *o16 = reinterpret_cast<uint16_t *>(stage) + mis16_0 + (uint32_t)u * row + qK;
                 const float v_ants = (L.b_pres[wd] & bit) ? 1.0f : 0.0f;  // :142
                 const float v_area = (area[wd] & bit) ? 1.0f : 0.0f;       // :130-131
                 const float v_wall = (walls[wd] & bit) ? 1.0f : 0.0f;      // :128-129
@@ -491,23 +491,29 @@ k_act(const KP p, const int8_t *__restrict__ rotation, const int8_t *__restrict_
                         o[k] = m ? v : -1.0f;
                     }
                 }
-                if (OBS16) { // bfloat16 rows are copied out one by one
-                    wave_lds_sync();
-                    // one 16-byte store per lane over the whole 8-element groups of the aligned window
-                    // [mis16, mis16 + row) (<= 60 groups), one 2-byte store for the <= 14 edge elements
-                    uint16_t *st16 = reinterpret_cast<uint16_t *>(stage), *d_al = dst16 - mis16;
-                    const uint32_t g_lo = (mis16 + 7) >> 3, g_hi = (mis16 + row) >> 3;
-                    const uint32_t ga = min(g_lo + (uint32_t)lane, g_hi - 1);
-                    const uint4 wa = reinterpret_cast<const uint4 *>(st16)[ga];
-                    const uint32_t hd16 = 8 * g_lo - mis16, tl16 = mis16 + row - 8 * g_hi;
-                    const uint32_t fe16 = (uint32_t)lane < hd16 ? mis16 + lane
-                                          : ((uint32_t)lane - hd16 < tl16 ? 8 * g_hi + ((uint32_t)lane - hd16) : mis16);
-                    const uint16_t we = st16[fe16];
-                    store_stream(reinterpret_cast<uint4 *>(d_al) + ga, wa);
-                    store_stream(d_al + fe16, we);
-                    wave_lds_sync();
-                    continue;
-                }
+            }
+            if (OBS16) {
+                // the group's bfloat16 rows as one run: two 16-byte stores per lane over the whole 8-element
+                // pieces (the first 64 start on a 128-byte line), one 2-byte store for the <= 14 edge elements
+                wave_lds_sync();
+                const uint32_t rowp = (i0 + 1 < i_end) ? 2u * row : row;
+                uint16_t *dst16 = reinterpret_cast<uint16_t *>(obs) + ((size_t)e * N + (size_t)i0) * row;
+                const uint32_t mis16 = (uint32_t)(((uintptr_t)dst16 >> 1) & 7);
+                uint16_t *st16 = reinterpret_cast<uint16_t *>(stage), *d_al = dst16 - mis16;
+                const uint32_t g_lo = (mis16 + 7) >> 3, g_hi = (mis16 + rowp) >> 3;
+                const uint32_t head = (g_hi - g_lo >= 72u) ? ((8u - (((uint32_t)((uintptr_t)d_al >> 4) + g_lo) & 7u)) & 7u) : 0u;
+                const uint32_t g1 = min(g_lo + head + (uint32_t)lane, g_hi - 1);
+                const uint32_t g2 = min((uint32_t)lane < head ? g_lo + (uint32_t)lane : g_lo + 64u + (uint32_t)lane, g_hi - 1);
+                const uint4 w1 = reinterpret_cast<const uint4 *>(st16)[g1];
+                const uint4 w2 = reinterpret_cast<const uint4 *>(st16)[g2];
+                const uint32_t hd16 = 8 * g_lo - mis16, tl16 = mis16 + rowp - 8 * g_hi;
+                const uint32_t fe16 = (uint32_t)lane < hd16 ? mis16 + lane
+                                      : ((uint32_t)lane - hd16 < tl16 ? 8 * g_hi + ((uint32_t)lane - hd16) : mis16);
+                const uint16_t we = st16[fe16];
+                store_stream(reinterpret_cast<uint4 *>(d_al) + g1, w1);
+                store_stream(reinterpret_cast<uint4 *>(d_al) + g2, w2);
+                store_stream(d_al + fe16, we);
+                wave_lds_sync();
             }
             if (!OBS16) {
                 // copy the group out: its rows are contiguous in memory, so the (up to) two rows leave as ONE
