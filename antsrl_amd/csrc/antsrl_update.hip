@@ -52,6 +52,7 @@ k_update_one(const KP p, const double *__restrict__ wall_jitter, const int out_b
     double x = p.s.x[a], y = p.s.y[a];
     const double px0 = p.s.prev_x[a], py0 = p.s.prev_y[a]; // used on a wall hit only; prefetched all the same
     const uint8_t rstate = p.s.reward_state[a];
+    const double theta0 = p.s.theta[a]; // used on a wall hit only
     float act[C];
 #pragma unroll
     for (int c = 0; c < C; ++c) act[c] = p.s.activation[a * C + c];
@@ -71,7 +72,8 @@ k_update_one(const KP p, const double *__restrict__ wall_jitter, const int out_b
         hkeys[h] = HASH_EMPTY;
         hvals[h] = 0u;
     }
-    const float food_dc = dc >= 0 ? food[dc] : 0.0f; // nobody else touches a dirty cell during the update
+    const float food_dc_l = food[dc_l >= 0 ? dc_l : 0]; // nobody else touches a dirty cell during the update
+    const float food_dc = dc >= 0 ? food_dc_l : 0.0f;
 
     // ---- Walls.update, walls.py:25-28
     const bool hit = on && test_bit(walls, (uint32_t)((int)x * H + (int)y));
@@ -87,7 +89,7 @@ k_update_one(const KP p, const double *__restrict__ wall_jitter, const int out_b
     if (hit) {
         x = px0;
         y = py0;
-        p.s.theta[a] += u - 0.5; // theta is NOT re-wrapped here
+        p.s.theta[a] = theta0 + (u - 0.5); // theta is NOT re-wrapped here
     }
 
     // ---- CircleObstacles.update, circle_obstacles.py:35-58
@@ -156,6 +158,12 @@ k_update_one(const KP p, const double *__restrict__ wall_jitter, const int out_b
     // ---- Ants.update, ants.py:123-130: prev := cur; deposit (pheromone.py:36-41)
     __syncthreads(); // the hash table is initialised (R == 0 and library jitter: no barrier so far)
     const uint32_t cell = (uint32_t)((int)x * H + (int)y);
+    // the deposit cell's old values, loaded by every ant ahead of the barriers (only the cell's winner uses
+    // them; no other ant writes this cell in this update except the wall-deposit clear, and a deposit on a
+    // wall cell ignores the old value)
+    float pold[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) pold[c] = out[(size_t)cell * PS + c];
     if (on) {
         if (moved) {
             p.s.x[a] = x;
@@ -183,7 +191,7 @@ k_update_one(const KP p, const double *__restrict__ wall_jitter, const int out_b
 #pragma unroll
                 for (int c = 0; c < C; ++c) {
                     if (act[c] != 0.0f) {
-                        float v = out[(size_t)cell * PS + c] + act[c];
+                        float v = pold[c] + act[c];
                         if (p.has_max_val) v = fminf(v, (float)p.max_val);
                         out[(size_t)cell * PS + c] = v;
                     }
@@ -194,7 +202,7 @@ k_update_one(const KP p, const double *__restrict__ wall_jitter, const int out_b
 #pragma unroll
                 for (int c = 0; c < C; ++c) {
                     if (act[c] != 0.0f) {
-                        double v = (double)out[(size_t)cell * PS + c] * p.g_dep;
+                        double v = (double)pold[c] * p.g_dep;
                         if (v < p.threshold || on_wall) v = 0.0;
                         v += (double)act[c];
                         if (p.has_max_val) v = fmin(v, p.max_val);

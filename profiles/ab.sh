@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B of library variants on ONE box (boxes differ by +-10 %): alternating bench runs.
-#   build here:  profiles/ab.sh build <name> [git-rev]   -> antsrl_amd/lib/variants/<name>.so
+#   build here:  [AB_FLAGS=-D...] profiles/ab.sh build <name> [git-rev]   -> antsrl_amd/lib/variants/<name>.so
 #   on the GPU:  profiles/ab.sh run <nameA> <nameB> [rounds] [extra bench args...]
 R=${GRAFT_REPO_ROOT:-/root/repo}
 V=$R/antsrl_amd/lib/variants
@@ -11,7 +11,7 @@ if [ "$1" = build ]; then
     for f in $(git -C $R ls-tree --name-only $3 antsrl_amd/csrc/); do git -C $R show $3:$f > $tmp/$f; done
     git -C $R show $3:include/antsrl.h > $tmp/include/antsrl.h; src=$tmp/antsrl_amd/csrc
   fi
-  hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared -std=c++17 -Wno-unused-function \
+  hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared -std=c++17 -Wno-unused-function $AB_FLAGS \
     $src/*.hip -o $V/$2.so && echo built $V/$2.so
   exit $?
 fi
