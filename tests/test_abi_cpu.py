@@ -43,13 +43,16 @@ def test_workspace_bytes_and_validation(lib):
     cfg = make_cfg(1024, 512, 256, 256, n_rocks=8)
     n = C.c_size_t()
     assert lib.antsrl_workspace_bytes(C.byref(cfg), C.byref(n)) == 0
-    # scaled pheromone units: ONE pheromone buffer + food + bitmaps + ant SoA, ~0.8 GiB
-    assert 0.75 * 2 ** 30 < n.value < 0.9 * 2 ** 30
+    # scaled pheromone units, two channels: ONE array of 16-byte {p0, p1, food, pad} cell records
+    # (1 GiB) + bitmaps + ant SoA
+    cells = 1024 * 256 * 256
+    assert 16 * cells < n.value < 16 * cells + 0.1 * 2 ** 30
     from antsrl_amd.config import PHERO_EXPLICIT_SWEEP
     cfg2 = make_cfg(1024, 512, 256, 256, n_rocks=8, phero_mode=PHERO_EXPLICIT_SWEEP)
     n2 = C.c_size_t()
     assert lib.antsrl_workspace_bytes(C.byref(cfg2), C.byref(n2)) == 0
-    assert n2.value - n.value == 1024 * 256 * 256 * 2 * 4  # the ping-pong buffer of the explicit sweep
+    # explicit sweep: two [cell][2] float32 pheromone buffers (ping-pong) + a separate food array
+    assert n2.value - n.value == cells * (2 * 8 + 4) - cells * 16
     bad = cfg.copy()
     bad.n_phero = 9
     assert lib.antsrl_workspace_bytes(C.byref(bad), C.byref(n)) == -1
