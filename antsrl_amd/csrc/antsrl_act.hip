@@ -34,7 +34,7 @@ struct ActOff {
 };
 
 __host__ __device__ __forceinline__ ActOff act_offsets(int N, int PP, int words, int HT, int K, int nwaves,
-                                                       bool static_lds, int R)
+                                                       bool static_lds, int R, bool big = false)
 {
     ActOff o;
     size_t off = 0;
@@ -47,8 +47,8 @@ __host__ __device__ __forceinline__ ActOff act_offsets(int N, int PP, int words,
     o.off = take(sizeof(CellOff) * (size_t)PP);
     o.cnt = take(4 * (size_t)N);
     o.rm = take(4 * (size_t)N);
-    o.pres = take(4 * (size_t)words);
-    o.old = take(4 * (size_t)words);
+    o.pres = take(big ? 0 : 4 * (size_t)words); // big: both maps live in HBM (DState::big_pres / big_old)
+    o.old = take(big ? 0 : 4 * (size_t)words);
     o.walls = o.area = 0;
     if (static_lds) {
         o.walls = take(4 * (size_t)words);
@@ -68,9 +68,10 @@ __host__ __device__ __forceinline__ ActOff act_offsets(int N, int PP, int words,
 }
 
 __host__ __device__ __forceinline__ size_t act_lds_bytes(int N, int PP, int words, int HT, int K, int nwaves,
-                                                         bool static_lds, void *, unsigned char *, int R = 0)
+                                                         bool static_lds, void *, unsigned char *, int R = 0,
+                                                         bool big = false)
 {
-    return act_offsets(N, PP, words, HT, K, nwaves, static_lds, R).total;
+    return act_offsets(N, PP, words, HT, K, nwaves, static_lds, R, big).total;
 }
 
 // Perception-channel layouts known at compile time (straight-line output code); anything else
@@ -110,7 +111,9 @@ extern "C" int antsrl_debug_read_act_trace(unsigned long long *dst, int n_wg)
 // LDS carve (`ActLds`), its pointers go through scratch and every LDS access degrades to flat_*.
 // TPB = threads per workgroup (512 or 1024); 4 waves per SIMD (<= 128 VGPRs) is all the LDS plans
 // can use (capping at 80 VGPRs for a third workgroup per CU measured slower, see plan_act).
-template <int C, bool STATIC_LDS, int LAYOUT, bool FAST, int TPB, bool OBS16 = false, bool ILV = false>
+// BIG: a grid whose presence / explored bit maps do not fit the workgroup's LDS keeps both in HBM scratch
+// (DState::big_pres / big_old, generic loop only): same code, the two pointers change address space.
+template <int C, bool STATIC_LDS, int LAYOUT, bool FAST, int TPB, bool OBS16 = false, bool ILV = false, bool BIG = false>
 __global__ void __launch_bounds__(TPB, 4)
 k_act(const KP p, const int8_t *__restrict__ rotation, const int8_t *__restrict__ phero_act, const int cur,
       float *__restrict__ obs, float *__restrict__ agent_state, float *__restrict__ reward,
@@ -122,14 +125,19 @@ k_act(const KP p, const int8_t *__restrict__ rotation, const int8_t *__restrict_
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwaves = T >> 6;
     const int N = p.N, W = p.W, H = p.H, K = p.K, P = p.P, PP = p.PP, R = p.R;
     const size_t G = (size_t)W * H;
-    const ActOff lo = act_offsets(N, PP, p.words, p.HT, K, nwaves, STATIC_LDS, R);
+    const ActOff lo = act_offsets(N, PP, p.words, p.HT, K, nwaves, STATIC_LDS, R, BIG);
     ActLds L; // filled field by field right here: never has its address taken, stays in registers
     L.frame = (AntFrame *)(smem + lo.frame);
     L.off = (CellOff *)(smem + lo.off);
     L.cnt = (uint32_t *)(smem + lo.cnt);
     L.rockmask = (uint32_t *)(smem + lo.rm);
-    L.b_pres = (uint32_t *)(smem + lo.pres);
-    L.b_old = (uint32_t *)(smem + lo.old);
+    if (BIG) {
+        L.b_pres = p.s.big_pres + (size_t)blockIdx.x * p.words;
+        L.b_old = p.s.big_old + (size_t)blockIdx.x * p.words;
+    } else {
+        L.b_pres = (uint32_t *)(smem + lo.pres);
+        L.b_old = (uint32_t *)(smem + lo.old);
+    }
     L.b_walls = (uint32_t *)(smem + lo.walls);
     L.b_area = (uint32_t *)(smem + lo.area);
     L.t_mask = smem + lo.mask;
@@ -629,7 +637,10 @@ k_act(const KP p, const int8_t *__restrict__ rotation, const int8_t *__restrict_
                 const uint32_t mis = (uint32_t)(((uintptr_t)dst >> 2) & 3);
                 if (valid[u]) {
                     float *o = stage + mis + (uint32_t)q * K;
-                    const float v_ants = (L.b_pres[wd] & bit) ? 1.0f : 0.0f;  // :142
+                    // (BIG: the map was built by L2 atomics, read it past the CU's L1)
+                    const uint32_t presw = BIG ? __hip_atomic_load(&L.b_pres[wd], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                               : L.b_pres[wd];
+                    const float v_ants = (presw & bit) ? 1.0f : 0.0f;  // :142
                     const float v_area = (area[wd] & bit) ? 1.0f : 0.0f;       // :130-131
                     const float v_wall = (walls[wd] & bit) ? 1.0f : 0.0f;      // :128-129
                     float v_rock = 0.0f;                                       // :132-135
@@ -758,6 +769,7 @@ struct ActPlan {
     int threads;
     bool static_lds;
     size_t lds;
+    bool big; // presence / explored maps in HBM scratch (grids past ~600k cells)
 };
 
 // LDS budget: 160 KiB per CU.  Preference order is MEASURED (c3, MI355X, profiles/plans.sh): the
@@ -784,6 +796,13 @@ static ActPlan plan_act(const KP &p)
         if (pin >= 0 ? k == pin : pl.lds <= c.limit) return pl;
         ++k;
     }
+    if (pin < 0) { // nothing fits with the grid's bit maps in LDS: keep them in HBM
+        for (size_t limit : {cap / 2, cap}) {
+            pl.threads = 512; pl.static_lds = false; pl.big = true;
+            pl.lds = act_lds_bytes(p.N, p.PP, p.words, p.HT, p.K, 8, false, nullptr, nullptr, p.R, true);
+            if (pl.lds <= limit) return pl;
+        }
+    }
     return pl; // caller checks pl.lds <= cap
 }
 
@@ -798,19 +817,19 @@ static int act_layout(const KP &p)
     return p.K == 6 ? LAYOUT_DEFAULT : LAYOUT_DEFAULT_ROCKS;
 }
 
-template <int C, bool ST, int LAYOUT, bool FAST, int TPB, bool OBS16 = false, bool ILV = false>
+template <int C, bool ST, int LAYOUT, bool FAST, int TPB, bool OBS16 = false, bool ILV = false, bool BIG = false>
 static hipError_t launch_act_t(const KP &p, const ActPlan &pl, const int8_t *rot, const int8_t *ph, int cur,
                                float *obs, float *agent_state, float *reward, uint8_t *done, int flags,
                                const double *jitter, int out_buf, hipStream_t st)
 {
     static size_t attr_lds = 0; // dynamic-LDS opt-in is per kernel function, set once per size
     if (pl.lds > attr_lds) {
-        hipError_t err = hipFuncSetAttribute((const void *)k_act<C, ST, LAYOUT, FAST, TPB, OBS16, ILV>,
+        hipError_t err = hipFuncSetAttribute((const void *)k_act<C, ST, LAYOUT, FAST, TPB, OBS16, ILV, BIG>,
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds);
         if (err != hipSuccess) return err;
         attr_lds = pl.lds;
     }
-    hipLaunchKernelGGL((k_act<C, ST, LAYOUT, FAST, TPB, OBS16, ILV>), dim3(p.E), dim3(TPB), pl.lds, st, p, rot, ph, cur, obs,
+    hipLaunchKernelGGL((k_act<C, ST, LAYOUT, FAST, TPB, OBS16, ILV, BIG>), dim3(p.E), dim3(TPB), pl.lds, st, p, rot, ph, cur, obs,
                        agent_state, reward, done, flags, jitter, out_buf);
     return hipGetLastError();
 }
@@ -839,7 +858,7 @@ static hipError_t launch_act_c(const KP &p, const int8_t *rot, const int8_t *ph,
     // the pipelined loop: one pass (PP <= 64), row of 8..368 floats (a group of two rows leaves in three
     // 16-byte stores per lane), observation wanted, no ablation
     const bool fast = C == 2 && layout != LAYOUT_GENERIC && p.PP <= 64 && row >= 8 && row <= 368 && obs &&
-                      !(flags & 0x700); // (ACT_ABL_NO_EXPLORE is honoured by the pipelined loop too)
+                      !(flags & 0x700) && !pl.big; // (ACT_ABL_NO_EXPLORE is honoured by the pipelined loop too)
 #define ACT_GO(ST, LY, FA) \
     return launch_act_k<C, ST, LY, FA>(p, pl, rot, ph, cur, obs, agent_state, reward, done, flags, jitter, out_buf, st)
 #define ACT_GOF(ST, LY, O16, IL) \
@@ -852,6 +871,9 @@ static hipError_t launch_act_c(const KP &p, const int8_t *rot, const int8_t *ph,
     }
     const bool o16 = (flags & ACT_OBS_BF16) != 0, ilv = p.ps == 4 && p.fs == 4;
     if (o16 && (!fast || C != 2)) return hipErrorNotSupported; // bfloat16 observations: pipelined loop only
+    if (pl.big) // generic loop, generic channel selection, 512 threads
+        return launch_act_t<C, false, LAYOUT_GENERIC, false, 512, false, false, true>(p, pl, rot, ph, cur, obs, agent_state, reward,
+                                                                                      done, flags, jitter, out_buf, st);
     if constexpr (C == 2) {
         if (layout != LAYOUT_GENERIC) {
             if (layout == LAYOUT_DEFAULT) {
@@ -884,3 +906,4 @@ hipError_t antsrl_launch_act(const KP &p, const int8_t *rot, const int8_t *ph, i
 }
 
 bool antsrl_act_fits(const KP &p) { return plan_act(p).lds <= 160 * 1024; }
+bool antsrl_act_needs_hbm_maps(const KP &p) { return plan_act(p).big; }

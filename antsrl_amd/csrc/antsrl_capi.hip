@@ -18,6 +18,7 @@ hipError_t antsrl_launch_act(const KP &p, const int8_t *rot, const int8_t *ph, i
                              float *agent_state, float *reward, uint8_t *done, int flags,
                              const double *jitter, int out_buf, hipStream_t st);
 bool antsrl_act_fits(const KP &p);
+bool antsrl_act_needs_hbm_maps(const KP &p);
 hipError_t antsrl_launch_sweep(const KP &p, int cur, hipStream_t st);
 hipError_t antsrl_launch_update(const KP &p, const double *jitter, int out_buf, hipStream_t st);
 hipError_t antsrl_launch_collect_full(const KP &p, hipStream_t st);
@@ -120,6 +121,8 @@ static bool use_interleaved(const AntsCfg *c)
     return !off && use_scaled(c) && c->n_phero == 2;
 }
 
+static void fill_kp(const AntsCfg *c, KP *p);
+
 // Carves the workspace; with base == NULL only computes the size.
 static size_t carve(const AntsCfg *c, DState *s, unsigned char *base)
 {
@@ -151,6 +154,15 @@ static size_t carve(const AntsCfg *c, DState *s, unsigned char *base)
     }
     d.walls_bits = (uint32_t *)take(4 * E * words); d.area_bits = (uint32_t *)take(4 * E * words);
     d.explored_bits = (uint32_t *)take(4 * E * words);
+    d.big_pres = d.big_old = nullptr;
+    {
+        KP kp;
+        fill_kp(c, &kp);
+        if (antsrl_act_needs_hbm_maps(kp)) {
+            d.big_pres = (uint32_t *)take(4 * E * words);
+            d.big_old = (uint32_t *)take(4 * E * words);
+        }
+    }
     d.anthill_xyr = (int32_t *)take(4 * E * 3);
     d.anthill_food = (double *)take(8 * E);
     d.rock_cx = (double *)take(8 * E * (R ? R : 1)); d.rock_cy = (double *)take(8 * E * (R ? R : 1));
@@ -278,8 +290,9 @@ extern "C" int antsrl_create(const AntsCfg *cfg, void *workspace, size_t workspa
     if (!antsrl_act_fits(h->p)) {
         delete h;
         return fail(ANTSRL_E_UNSUPPORTED,
-                    "grid %dx%d with %d ants needs more than 160 KiB of LDS per workgroup "
-                    "(bit-packed explored/presence maps are kept in LDS)", cfg->w, cfg->h, cfg->n_ants);
+                    "%d ants with a %dx%d perception need more than 160 KiB of LDS per workgroup "
+                    "(per-ant frames, the collision hash and the row staging are kept in LDS)", cfg->n_ants,
+                    2 * cfg->perception_radius + 1, 2 * cfg->perception_radius + 1);
     }
     *out = h;
     return ANTSRL_OK;
@@ -330,7 +343,8 @@ extern "C" int antsrl_generate(AntsHandle *h, const AntsGen *gen, uint64_t episo
 static int bf16_unsupported()
 {
     return fail(ANTSRL_E_UNSUPPORTED, "bfloat16 observations need 2 pheromone channels, the generator's channel order "
-                                      "([Ants, Phero0, Phero1, Anthill, Walls, Food(, Rocks)]) and a perception of at most 64 cells");
+                                      "([Ants, Phero0, Phero1, Anthill, Walls, Food(, Rocks)]), a perception of at most 64 cells and a grid "
+                                      "whose bit maps fit LDS (up to ~600k cells)");
 }
 
 extern "C" int antsrl_set_obs_format(AntsHandle *h, int format)

@@ -36,6 +36,8 @@ struct DState {
                                              //  = 4, food = phero[0] + 2 — a perception is then a single
                                              //  16-byte gather per cell)
     uint32_t *walls_bits, *area_bits, *explored_bits; // [E*words]
+    uint32_t *big_pres, *big_old; // [E*words] presence / pre-step explored map of k_act when the grid's bit maps do
+                                  // not fit LDS (antsrl_act_needs_hbm_maps), else NULL
     int32_t *anthill_xyr;                    // [E*3]
     double *anthill_food;                    // [E]
     double *rock_cx, *rock_cy, *rock_r, *rock_w; // [E*R]

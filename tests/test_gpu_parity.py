@@ -423,6 +423,25 @@ def test_known_answers(torch_mod):
     assert set(np.unique(o[:, mask, 0])) <= {0.0, 1.0}
 
 
+def test_large_grids_and_many_envs(torch_mod):
+    """The ends of the size range: grids whose presence / explored bit maps do not fit the workgroup's
+    LDS and live in HBM scratch (1024 x 768, 1024 x 1024), a long thin grid, and thousands of tiny envs
+    in one handle (grid dimension = env count), with and without the explicit sweep kernel."""
+    from antsrl_amd import config as cm
+    from antsrl_amd.synth import synth_init
+    for (E, N, W, H, kw, steps) in [
+        (1, 200, 1024, 768, dict(n_rocks=3, deposit_strength=256.0), 3),
+        (2, 300, 1024, 1024, dict(deposit_strength=256.0, reward_kind=cm.REWARD_ALL, fct_explore_holding=0.5), 3),
+        (2, 64, 2048, 16, dict(deposit_strength=256.0), 3),
+        (1, 96, 640, 640, dict(deposit_strength=256.0, phero_mode=cm.PHERO_EXPLICIT_SWEEP), 2),
+        (3000, 3, 16, 16, dict(deposit_strength=256.0), 3),
+        (2500, 5, 16, 24, dict(n_rocks=1, deposit_strength=256.0, phero_mode=cm.PHERO_EXPLICIT_SWEEP), 2),
+    ]:
+        cfg = cm.make_cfg(E, N, W, H, **kw)
+        init = synth_init(cfg, seed=17, n_food_discs=5, food_rmin=2, food_rmax=5)
+        _compare_with_oracle(torch_mod, cfg, init, steps=steps, seed=6, jitter_mode="builtin")
+
+
 def test_bfloat16_observation_format(torch_mod):
     """antsrl_set_obs_format(BF16): the observation tensor holds exactly the float32 observation rounded
     to nearest even, for both default layouts (with and without rocks), odd row alignments and an odd
