@@ -83,11 +83,26 @@ def test_create_rejects_bad_workspace(lib):
 
 
 def test_lds_budget_is_checked(lib):
-    cfg = make_cfg(1, 64, 2048, 2048)  # 3 x 512 KiB bitmaps cannot live in 160 KiB of LDS
+    """Grids of any size are accepted (past ~600k cells the per-env bit maps move to HBM scratch, which
+    the workspace then includes); an ant count whose per-ant frames cannot live in 160 KiB of LDS is
+    refused at create time."""
     n = C.c_size_t()
-    lib.antsrl_workspace_bytes(C.byref(cfg), C.byref(n))
+    n_small = C.c_size_t()
+    cfg = make_cfg(1, 64, 2048, 2048)
+    assert lib.antsrl_workspace_bytes(C.byref(cfg), C.byref(n)) == 0
     h = C.c_void_p()
+    assert lib.antsrl_create(C.byref(cfg), C.c_void_p(4096), n.value, C.byref(h)) == 0
+    lib.antsrl_destroy(h)
+    words = 2048 * 2048 // 32
+    # 16-byte cell records + walls / anthill / explored maps + the presence and pre-step explored maps
+    assert n.value >= 16 * 2048 * 2048 + 5 * 4 * words
+    cfg_s = make_cfg(1, 64, 512, 512)  # bit maps in LDS: no scratch maps in the workspace
+    assert lib.antsrl_workspace_bytes(C.byref(cfg_s), C.byref(n_small)) == 0
+    assert n_small.value < 16 * 512 * 512 + 4 * 4 * (512 * 512 // 32) + 65536
+    cfg = make_cfg(1, 6000, 64, 64)
+    lib.antsrl_workspace_bytes(C.byref(cfg), C.byref(n))
     assert lib.antsrl_create(C.byref(cfg), C.c_void_p(4096), n.value, C.byref(h)) == -4
+    assert b"LDS" in lib.antsrl_last_error()
 
 
 def test_product_never_imports_oracle():
