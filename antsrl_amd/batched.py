@@ -30,6 +30,12 @@ _STATE_DTYPES = {
 }
 
 
+import contextlib
+
+_NULL_CTX = contextlib.nullcontext()
+_RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else C.c_void_p(t.data_ptr())
 
@@ -47,6 +53,7 @@ class BatchedAntsEnv:
         self.lib = _lib.load()
         self.cfg = cfg.copy()
         self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
+        self._dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
         need = C.c_size_t()
         _lib.check(self.lib.antsrl_workspace_bytes(C.byref(self.cfg), C.byref(need)), "workspace_bytes")
         self.workspace_bytes = need.value
@@ -58,13 +65,31 @@ class BatchedAntsEnv:
             _lib.check(self.lib.antsrl_create(C.byref(self.cfg), C.c_void_p(self._ws_ptr), need.value,
                                               C.byref(self._h)), "create")
             E, N, P, K = cfg.n_envs, cfg.n_ants, cfg.pside, cfg.n_channels
-            self.obs = torch.empty((E, N, P, P, K), dtype=obs_dtype, device=self.device)
+            # The four step outputs are views of ONE device buffer (256-byte aligned pieces, the small ones
+            # first): outputs_to_host() brings them over in a single copy.
+            esz = 4 if obs_dtype == torch.float32 else 2
+            sizes = [("agent_state", E * N * 2 * 4), ("reward", E * N * 4), ("done", E), ("obs", E * N * P * P * K * esz)]
+            offs, total = {}, 0
+            for name, nbytes in sizes:
+                offs[name] = total
+                total += (nbytes + 255) // 256 * 256
+            self._out_flat = torch.zeros((total + 256,), dtype=torch.uint8, device=self.device)
+            base = (-self._out_flat.data_ptr()) % 256
+            self._out_flat = self._out_flat[base:base + total]
+            self._out_offs, self._small_bytes = offs, offs["obs"]
+
+            def piece(name, nbytes, dtype, shape):
+                return self._out_flat[offs[name]:offs[name] + nbytes].view(dtype).view(shape)
+            self.obs = piece("obs", sizes[3][1], obs_dtype, (E, N, P, P, K))
             if obs_dtype == torch.bfloat16:
                 _lib.check(self.lib.antsrl_set_obs_format(self._h, 1), "set_obs_format")
-            self.agent_state = torch.empty((E, N, 2), dtype=torch.float32, device=self.device)
-            self.reward = torch.empty((E, N), dtype=torch.float32, device=self.device)
-            self.done = torch.zeros((E,), dtype=torch.uint8, device=self.device)
+            self.agent_state = piece("agent_state", sizes[0][1], torch.float32, (E, N, 2))
+            self.reward = piece("reward", sizes[1][1], torch.float32, (E, N))
+            self.done = piece("done", sizes[2][1], torch.uint8, (E,))
         self._keep = None
+        self._host_out = None   # pinned mirror of _out_flat (outputs_to_host)
+        self._host_act = None   # pinned staging of numpy actions + the event of its last upload
+        self._act_event = None
 
     def __del__(self):
         h = getattr(self, "_h", None)
@@ -74,7 +99,13 @@ class BatchedAntsEnv:
 
     # ------------------------------------------------------------------ helpers
     def _stream(self):
+        if _RAW_STREAM is not None:  # same value as current_stream(device).cuda_stream, without the Stream object
+            return C.c_void_p(_RAW_STREAM(self._dev_index))
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _on_device(self):
+        """Context that makes self.device current for a launch (a no-op when it already is)."""
+        return _NULL_CTX if torch.cuda.current_device() == self._dev_index else torch.cuda.device(self.device)
 
     def _dev(self, a, dtype, shape=None):
         if a is None:
@@ -116,14 +147,56 @@ class BatchedAntsEnv:
 
     def _actions(self, rotation, phero):
         c = self.cfg
+        if isinstance(rotation, np.ndarray) and isinstance(phero, np.ndarray):
+            # host actions: both arrays through one pinned staging buffer, ONE upload
+            n = c.n_envs * c.n_ants
+            if self._host_act is None:
+                self._host_act = torch.empty((2, c.n_envs, c.n_ants), dtype=torch.int8, pin_memory=True)
+                self._dev_act = torch.empty((2, c.n_envs, c.n_ants), dtype=torch.int8, device=self.device)
+                self._act_event = torch.cuda.Event()
+            else:
+                self._act_event.synchronize()  # the previous upload has left the staging buffer
+            assert rotation.size == n and phero.size == n, "expected %d actions per array" % n
+            h = self._host_act.numpy()
+            h[0] = rotation.reshape(c.n_envs, c.n_ants)
+            h[1] = phero.reshape(c.n_envs, c.n_ants)
+            with torch.cuda.device(self.device):
+                self._dev_act.copy_(self._host_act, non_blocking=True)
+                self._act_event.record()
+            return self._dev_act[0], self._dev_act[1]
         rot = self._dev(rotation, torch.int8, (c.n_envs, c.n_ants))
         ph = self._dev(phero, torch.int8, (c.n_envs, c.n_ants))
         return rot, ph
 
+    def outputs_to_host(self, want_obs: bool = True):
+        """(obs, agent_state, reward, done) of the last step as fresh numpy arrays: ONE device-to-host copy
+        of the packed output buffer into pinned memory (obs left out when not wanted), then host copies."""
+        if self.obs.dtype != torch.float32 and want_obs:
+            raise _lib.AntsrlError("outputs_to_host: bfloat16 observations have no numpy dtype; use the device tensors")
+        base, o = self._out_flat.data_ptr(), self._out_offs
+        if any(t.data_ptr() != base + o[k] for k, t in (("obs", self.obs), ("agent_state", self.agent_state),
+                                                         ("reward", self.reward), ("done", self.done))):
+            # an output was re-pointed (e.g. at a RewardGather slot): plain per-tensor copies
+            return (self.obs.cpu().numpy() if want_obs else None, self.agent_state.cpu().numpy(),
+                    self.reward.cpu().numpy(), self.done.cpu().numpy())
+        if self._host_out is None:
+            self._host_out = torch.empty((self._out_flat.numel(),), dtype=torch.uint8, pin_memory=True)
+        n = self._out_flat.numel() if want_obs else self._small_bytes
+        with torch.cuda.device(self.device):
+            self._host_out[:n].copy_(self._out_flat[:n], non_blocking=True)
+            torch.cuda.current_stream(self.device).synchronize()
+        hb, o = self._host_out.numpy(), self._out_offs
+
+        def piece(name, t):
+            nb = t.numel() * t.element_size()
+            return hb[o[name]:o[name] + nb].view(np.float32 if t.dtype == torch.float32 else np.uint8).reshape(tuple(t.shape)).copy()
+        return (piece("obs", self.obs) if want_obs else None, piece("agent_state", self.agent_state),
+                piece("reward", self.reward), piece("done", self.done))
+
     def step(self, rotation, phero, want_obs: bool = True):
         """RLApi.step (RL_api.py:168-204) for all envs -> (obs, agent_state, reward, done)."""
         rot, ph = self._actions(rotation, phero)
-        with torch.cuda.device(self.device):
+        with self._on_device():
             _lib.check(self.lib.antsrl_step(self._h, _ptr(rot), _ptr(ph), _ptr(self.obs if want_obs else None),
                                             _ptr(self.agent_state), _ptr(self.reward), _ptr(self.done),
                                             self._stream()), "step")
@@ -131,7 +204,7 @@ class BatchedAntsEnv:
 
     def observe(self, want_obs: bool = True):
         """RLApi.observation (RL_api.py:96-165) -> (obs, agent_state, reward)."""
-        with torch.cuda.device(self.device):
+        with self._on_device():
             _lib.check(self.lib.antsrl_observe(self._h, _ptr(self.obs if want_obs else None),
                                                _ptr(self.agent_state), _ptr(self.reward), self._stream()),
                        "observe")
@@ -141,7 +214,7 @@ class BatchedAntsEnv:
         """Environment.update (environment.py:42-47)."""
         c = self.cfg
         j = self._dev(wall_jitter, torch.float64, (c.n_envs, c.n_ants))
-        with torch.cuda.device(self.device):
+        with self._on_device():
             _lib.check(self.lib.antsrl_update(self._h, _ptr(j), self._stream()), "update")
 
     def step_update(self, rotation, phero, wall_jitter=None, want_obs: bool = True):
@@ -149,7 +222,7 @@ class BatchedAntsEnv:
         c = self.cfg
         rot, ph = self._actions(rotation, phero)
         j = self._dev(wall_jitter, torch.float64, (c.n_envs, c.n_ants))
-        with torch.cuda.device(self.device):
+        with self._on_device():
             _lib.check(self.lib.antsrl_step_update(self._h, _ptr(rot), _ptr(ph), _ptr(j),
                                                    _ptr(self.obs if want_obs else None), _ptr(self.agent_state),
                                                    _ptr(self.reward), _ptr(self.done), self._stream()),

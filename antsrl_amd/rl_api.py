@@ -447,6 +447,12 @@ class RLApi(EnvObject):  # environment/RL_api.py:22-204
         """RL_api.py:168-204 -> (perception, agent_state, reward, done)."""
         b = self._backend
         obs, ast, rew, done = b.step(self._acts(rotation), self._acts(on_off_pheromones))
+        if self.as_numpy:  # the four outputs in one device-to-host copy
+            obs, ast, rew, done = b.outputs_to_host()
+            fold = lambda t: t.reshape((t.shape[0] * t.shape[1],) + t.shape[2:])
+            self.reward.rewards = r = fold(rew)
+            d = bool(done[0]) if b.cfg.n_envs == 1 else done.astype(bool)
+            return fold(obs), fold(ast), r, d
         r = self._out(rew)
         self.reward.rewards = r
         if b.cfg.n_envs == 1:

@@ -141,3 +141,35 @@ def test_snapshot_of_chosen_envs_from_the_batched_backend():
         np.testing.assert_array_equal(o["CircleObstaclesVisualization"].weights, init["rocks"][e][:, 3])
         np.testing.assert_array_equal(o["Walls"].map, init["walls"][e].astype(bool))
     assert len(S.loads(S.dumps(snaps))) == 2
+
+
+def test_outputs_to_host_matches_device_tensors():
+    """BatchedAntsEnv.outputs_to_host (one packed device-to-host copy) returns fresh arrays equal to the
+    device tensors, with numpy actions going up through the pinned staging buffer; a re-pointed output
+    (RewardGather slot) falls back to per-tensor copies."""
+    import torch
+    from antsrl_amd import config as cm
+    from antsrl_amd.batched import BatchedAntsEnv
+    from antsrl_amd.synth import random_actions, synth_init
+    cfg = cm.make_cfg(3, 37, 48, 40, n_rocks=2, deposit_strength=256.0)
+    init = synth_init(cfg, seed=4, n_food_discs=4, food_rmin=2, food_rmax=4)
+    a, b = BatchedAntsEnv(cfg), BatchedAntsEnv(cfg)
+    a.reset(init)
+    b.reset(init)
+    rot, ph = random_actions(cfg, 6, seed=3)
+    kept = []
+    for t in range(6):
+        a.step_update(torch.from_numpy(rot[t]).cuda(), torch.from_numpy(ph[t]).cuda())   # device tensors
+        b.step_update(rot[t].astype(np.int64), ph[t])                                       # numpy, any int dtype
+        out = b.outputs_to_host()
+        for got, ref in zip(out, (a.obs, a.agent_state, a.reward, a.done)):
+            np.testing.assert_array_equal(got, ref.cpu().numpy())
+        kept.append(out[0])
+    assert all(k.base is None or k.flags.owndata for k in kept)          # fresh arrays,
+    assert not np.array_equal(kept[0], kept[-1])                         # not views of one buffer
+    small = b.outputs_to_host(want_obs=False)
+    assert small[0] is None and np.array_equal(small[2], a.reward.cpu().numpy())
+    b.reward = torch.zeros_like(b.reward)                                 # re-pointed output
+    b.step_update(rot[0], ph[0])
+    a.step_update(rot[0], ph[0])
+    np.testing.assert_array_equal(b.outputs_to_host()[2], a.reward.cpu().numpy())
