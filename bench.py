@@ -41,6 +41,22 @@ CONFIGS = {
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 
+def measured_copy_gbs(dev, nbytes=1 << 30, reps=10):
+    """Device-to-device copy bandwidth on this box, GB/s of read + written bytes."""
+    import torch
+    src = torch.empty((nbytes // 4,), dtype=torch.float32, device=dev).normal_()
+    dst = torch.empty_like(src)
+    for _ in range(2):
+        dst.copy_(src)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        dst.copy_(src)
+    e1.record()
+    e1.synchronize()
+    return 2.0 * nbytes * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+
 def algorithmic_bytes(N, W, H, Cn, K, P=49, obs_bytes=4):
     """SURVEY.md §8(d) per env-step figure, split by the kernel that moves each term."""
     sweep = 2 * Cn * W * H * 4 + W * H                 # pheromone read+write sweep, wall mask
@@ -270,6 +286,12 @@ def main():
                             step_algorithmic_gbs=round(ab["total"] * E / (elapsed / K) / 1e9, 1))
         else:
             roofline = dict(bound="hbm", achieved=None, peak=HBM_PEAK_GBS, unit="GB/s", frac=None, traffic=None)
+        if timing and roofline.get("achieved"):
+            # the spec peak next to what a plain device copy reaches on THIS box
+            # (read + write bytes of a 1 GiB float32 copy, outside the timed region)
+            copy_gbs = measured_copy_gbs(dev)
+            roofline["measured_copy_gbs"] = round(copy_gbs, 1)
+            roofline["frac_of_measured_copy"] = round(roofline["achieved"] / copy_gbs, 4)
         value = world * E * cfg.n_ants * K / elapsed
         out = {
             "metric": "ant-steps/sec (ants x envs x steps/s), 256^2 grid" if cfg.w == 256 else "ant-steps/sec (ants x envs x steps/s)",
