@@ -11,8 +11,13 @@ Extensions over the reference (none changes its behaviour for the reference's ar
   * n_envs > 1 builds a batch; env e is drawn with seed + e (seed=None: fresh randomness each);
   * n_rocks > 0 works.  The reference's rock branch raises NameError (`n_rocks` undefined at
     environment_generator.py:83-84); this follows its evident intent (self.n_rocks).
-PerlinGenerator is not provided: it needs the third-party `noise` package (absent); walls are
-just an input bitmap to the path, any object with .generate(w, h) -> bool[w, h] works.
+PerlinGenerator (the walls of main.py:75) thresholds 2-D improved Perlin noise.  The reference gets the
+noise from the third-party `noise` package (utils.py:7-17, `noise.pnoise2`), which is absent here and
+not under /root/reference: `perlin_noise` below restates the published algorithm (Perlin 2002:
+permutation table, quintic fade, 16-entry gradient table, octaves summed as total/max) in float32.
+It could not be checked against the package, so equal seeds give the same KIND of cave map, not a
+pinned bit-identical one ("parity unpinned" for this generator; walls are an input bitmap to the
+path, any object with .generate(w, h) -> bool[w, h] works).
 """
 from __future__ import annotations
 
@@ -61,10 +66,80 @@ class EmptyGenerator:
         return np.zeros((w, h), dtype=bool)
 
 
+# Ken Perlin's reference permutation (Improved Noise, 2002)
+_PERM = np.array([
+    151, 160, 137, 91, 90, 15, 131, 13, 201, 95, 96, 53, 194, 233, 7, 225, 140, 36, 103, 30, 69, 142, 8, 99, 37, 240,
+    21, 10, 23, 190, 6, 148, 247, 120, 234, 75, 0, 26, 197, 62, 94, 252, 219, 203, 117, 35, 11, 32, 57, 177, 33, 88,
+    237, 149, 56, 87, 174, 20, 125, 136, 171, 168, 68, 175, 74, 165, 71, 134, 139, 48, 27, 166, 77, 146, 158, 231, 83,
+    111, 229, 122, 60, 211, 133, 230, 220, 105, 92, 41, 55, 46, 245, 40, 244, 102, 143, 54, 65, 25, 63, 161, 1, 216,
+    80, 73, 209, 76, 132, 187, 208, 89, 18, 169, 200, 196, 135, 130, 116, 188, 159, 86, 164, 100, 109, 198, 173, 186,
+    3, 64, 52, 217, 226, 250, 124, 123, 5, 202, 38, 147, 118, 126, 255, 82, 85, 212, 207, 206, 59, 227, 47, 16, 58, 17,
+    182, 189, 28, 42, 223, 183, 170, 213, 119, 248, 152, 2, 44, 154, 163, 70, 221, 153, 101, 155, 167, 43, 172, 9, 129,
+    22, 39, 253, 19, 98, 108, 110, 79, 113, 224, 232, 178, 185, 112, 104, 218, 246, 97, 228, 251, 34, 242, 193, 238,
+    210, 144, 12, 191, 179, 162, 241, 81, 51, 145, 235, 249, 14, 239, 107, 49, 192, 214, 31, 181, 199, 106, 157, 184,
+    84, 204, 176, 115, 121, 50, 45, 127, 4, 150, 254, 138, 236, 205, 93, 222, 114, 67, 29, 24, 72, 243, 141, 128, 195,
+    78, 66, 215, 61, 156, 180], dtype=np.int64)
+_PERM2 = np.concatenate([_PERM, _PERM])
+# gradient directions (x, y components of the 16-entry table of the improved noise)
+_GRAD = np.array([[1, 1], [-1, 1], [1, -1], [-1, -1], [1, 0], [-1, 0], [1, 0], [-1, 0],
+                  [0, 1], [0, -1], [0, 1], [0, -1], [1, 0], [-1, 0], [0, -1], [0, 1]], dtype=np.float32)
+
+
+def _noise2(x, y, repeatx, repeaty, base=0):
+    """One octave of 2-D improved Perlin noise on float32 arrays (tiles with period repeatx / repeaty)."""
+    f32 = np.float32
+    x, y = x.astype(f32), y.astype(f32)
+    i = np.floor(np.fmod(x, f32(repeatx))).astype(np.int64)
+    j = np.floor(np.fmod(y, f32(repeaty))).astype(np.int64)
+    ii = np.fmod((i + 1).astype(f32), f32(repeatx)).astype(np.int64)
+    jj = np.fmod((j + 1).astype(f32), f32(repeaty)).astype(np.int64)
+    i, j, ii, jj = (i & 255) + base, (j & 255) + base, (ii & 255) + base, (jj & 255) + base
+    x = x - np.floor(x)
+    y = y - np.floor(y)
+    fx = x * x * x * (x * (x * f32(6) - f32(15)) + f32(10))
+    fy = y * y * y * (y * (y * f32(6) - f32(15)) + f32(10))
+    A, B = _PERM2[i], _PERM2[ii]
+    AA, AB, BA, BB = _PERM2[A + j], _PERM2[A + jj], _PERM2[B + j], _PERM2[B + jj]
+
+    def grad(h, gx, gy):
+        g = _GRAD[_PERM2[h] & 15]
+        return gx * g[..., 0] + gy * g[..., 1]
+
+    def lerp(t, a, b):
+        return a + t * (b - a)
+    one = f32(1)
+    return lerp(fy, lerp(fx, grad(AA, x, y), grad(BA, x - one, y)),
+                lerp(fx, grad(AB, x, y - one), grad(BB, x - one, y - one)))
+
+
+def perlin_noise(w, h, offset_x, offset_y, scale=22.0, octaves=2, persistence=0.5, lacunarity=2.0):
+    """utils.py:7-17 (`perlin_noise_generator`): gen[i, j] = pnoise2((i + offset_x) / scale,
+    (j + offset_y) / scale, octaves, persistence, lacunarity, base=0), values in [-1, 1]."""
+    f32 = np.float32
+    x = ((np.arange(w, dtype=np.float64) + offset_x) / scale).astype(f32)[:, None] * np.ones((1, h), f32)
+    y = ((np.arange(h, dtype=np.float64) + offset_y) / scale).astype(f32)[None, :] * np.ones((w, 1), f32)
+    if octaves == 1:
+        return _noise2(x, y, 1024.0, 1024.0).astype(np.float64)
+    freq, amp, mx = f32(1), f32(1), f32(0)
+    total = np.zeros((w, h), f32)
+    for _ in range(octaves):
+        total = total + _noise2(x * freq, y * freq, 1024.0 * float(freq), 1024.0 * float(freq)) * amp
+        mx = f32(mx + amp)
+        freq = f32(freq * f32(lacunarity))
+        amp = f32(amp * f32(persistence))
+    return (total / mx).astype(np.float64)
+
+
 class PerlinGenerator:  # generator/map_generators.py:9-25
-    def __init__(self, *a, **k):
-        raise NotImplementedError("PerlinGenerator needs the third-party `noise` package, which is outside "
-                                  "the hot path; pass any object with .generate(w, h) -> bool[w, h]")
+    def __init__(self, scale=22.0, density=0.05, octaves=2, persistence=0.5, lacunarity=2.0):
+        self.scale, self.density, self.octaves = scale, density, octaves
+        self.persistence, self.lacunarity = persistence, lacunarity
+
+    def generate(self, w, h):
+        # two draws from the global `random` stream, like the reference (:19-20)
+        ox = random.randint(-10000, 10000)
+        oy = random.randint(-10000, 10000)
+        return perlin_noise(w, h, ox, oy, self.scale, self.octaves, self.persistence, self.lacunarity) > self.density
 
 
 class EnvironmentGenerator:  # generator/environment_generator.py:19-106

@@ -3,8 +3,8 @@
 Seeded per environment with numpy Generator(PCG64(seed + env_id)) on the host; mirrors what
 EnvironmentGenerator.generate builds (generator/environment_generator.py:52-106):
   * anthill centre uniform in the central half, radius int(u*0.05*min + 0.05*min)   (:60-63)
-  * walls Bernoulli(p) per cell, cleared on the anthill area (:66-68).  PerlinGenerator needs the
-    absent `noise` package; any bitmap is a valid input to the path.
+  * walls Bernoulli(p) per cell, cleared on the anthill area (:66-68); any bitmap is a valid input to
+    the path (antsrl_amd.generator.PerlinGenerator draws the reference's cave-like ones).
   * food = n discs of radius 5..10 (main.py:74, generator/map_generators.py:34-46), zeroed on
     walls (:72)
   * ants uniform in a disc of 0.8*radius around the anthill, theta uniform [0, 2pi)   (:87-91)

@@ -86,3 +86,40 @@ def test_reference_import_aliases():
         for k in [k for k in sys.modules if k.split(".")[0] in ("environment", "generator")]:
             del sys.modules[k]
         sys.modules.update(saved)
+
+
+def test_perlin_walls_generator():
+    """PerlinGenerator (generator/map_generators.py:9-25, the walls of main.py:75) on the restated improved
+    Perlin noise: properties of the published algorithm (the `noise` package itself is absent: unpinned)."""
+    from antsrl_amd.generator import PerlinGenerator, _PERM, _noise2, perlin_noise
+    assert sorted(_PERM.tolist()) == list(range(256))
+    # one octave vanishes on the integer lattice and stays within [-1, 1]
+    assert np.abs(perlin_noise(9, 7, 3, -4, scale=1.0, octaves=1)).max() == 0.0
+    n = perlin_noise(160, 120, -3456, 7890)  # defaults: scale 22, 2 octaves, persistence 0.5, lacunarity 2
+    assert n.shape == (160, 120) and n.dtype == np.float64 and -1.0 <= n.min() < -0.3 and 0.3 < n.max() <= 1.0
+    assert abs(n.mean()) < 0.1
+    # smooth at the scale of a cell (gradient <= ~ sqrt(2) * 1.5 / scale per octave-sum)
+    assert np.abs(np.diff(n, axis=0)).max() < 0.2 and np.abs(np.diff(n, axis=1)).max() < 0.2
+    # a shifted offset is the same field shifted
+    m = perlin_noise(160, 120, -3456 + 5, 7890 - 3)
+    np.testing.assert_allclose(m[:-5, 3:], n[5:, :-3], atol=1e-5)
+    # octaves: total / max of the amplitude-weighted single octaves
+    x = ((np.arange(40) + 11) / 22.0).astype(np.float32)[:, None] * np.ones((1, 30), np.float32)
+    y = ((np.arange(30) - 7) / 22.0).astype(np.float32)[None, :] * np.ones((40, 1), np.float32)
+    two = (_noise2(x, y, 1024.0, 1024.0) + 0.5 * _noise2(2 * x, 2 * y, 2048.0, 2048.0)) / 1.5
+    np.testing.assert_allclose(perlin_noise(40, 30, 11, -7), two, atol=1e-6)
+    # the generator: two draws from the global `random` stream, boolean map, reproducible under a seed
+    random.seed(12)
+    a = PerlinGenerator(scale=22.0, density=0.3).generate(96, 64)
+    after = random.random()
+    random.seed(12)
+    ox, oy = random.randint(-10000, 10000), random.randint(-10000, 10000)
+    assert random.random() == after
+    assert a.dtype == bool and a.shape == (96, 64)
+    np.testing.assert_array_equal(a, perlin_noise(96, 64, ox, oy) > 0.3)
+    fr = np.mean([PerlinGenerator(22.0, 0.3).generate(128, 128).mean() for _ in range(8)])
+    assert 0.005 < fr < 0.2  # sparse caves at main.py's density
+    # drives the episode generator like main.py:70-79
+    g = EnvironmentGenerator(48, 48, 8, 2, 0, CirclesGenerator(5, 2, 4), PerlinGenerator(scale=22.0, density=0.3), 100, seed=4)
+    d = g.draw()
+    assert d["walls"].shape == (1, 48, 48)
