@@ -94,12 +94,21 @@ class AntsCfg(C.Structure):
 class AntsGen(C.Structure):
     """Device-side episode generator parameters (include/antsrl.h: AntsGen)."""
     _fields_ = [("wall_density", C.c_double), ("n_food_discs", C.c_int32), ("food_rmin", C.c_int32),
-                ("food_rmax", C.c_int32), ("auto_reset", C.c_int32)]
+                ("food_rmax", C.c_int32), ("auto_reset", C.c_int32), ("wall_kind", C.c_int32),
+                ("perlin_octaves", C.c_int32), ("perlin_scale", C.c_double), ("perlin_persistence", C.c_double),
+                ("perlin_lacunarity", C.c_double)]
 
 
-def make_gen(wall_density=0.05, n_food_discs=20, food_rmin=5, food_rmax=10, auto_reset=False) -> AntsGen:
-    """Defaults: main.py:74 (CirclesGenerator(20, 5, 10)); walls 5 %."""
-    return AntsGen(wall_density, n_food_discs, food_rmin, food_rmax, 1 if auto_reset else 0)
+WALLS_BERNOULLI, WALLS_PERLIN = 0, 1
+
+
+def make_gen(wall_density=0.05, n_food_discs=20, food_rmin=5, food_rmax=10, auto_reset=False, walls="bernoulli",
+             perlin_scale=22.0, perlin_octaves=2, perlin_persistence=0.5, perlin_lacunarity=2.0) -> AntsGen:
+    """Defaults: main.py:74 (CirclesGenerator(20, 5, 10)); walls 5 % independent cells.
+    walls="perlin": PerlinGenerator(scale, density=wall_density, octaves, persistence, lacunarity), main.py:75."""
+    kind = {"bernoulli": WALLS_BERNOULLI, "perlin": WALLS_PERLIN}[walls]
+    return AntsGen(wall_density, n_food_discs, food_rmin, food_rmax, 1 if auto_reset else 0, kind,
+                   int(perlin_octaves), float(perlin_scale), float(perlin_persistence), float(perlin_lacunarity))
 
 
 class AntsInit(C.Structure):

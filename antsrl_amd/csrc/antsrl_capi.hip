@@ -334,7 +334,16 @@ extern "C" int antsrl_generate(AntsHandle *h, const AntsGen *gen, uint64_t episo
     if (gen->n_food_discs < 0 || gen->n_food_discs > ANTSRL_MAX_FOOD_DISCS)
         return fail(ANTSRL_E_INVALID, "n_food_discs must be in 0..%d", ANTSRL_MAX_FOOD_DISCS);
     if (gen->food_rmin < 0 || gen->food_rmax < gen->food_rmin) return fail(ANTSRL_E_INVALID, "bad food radii");
-    if (!(gen->wall_density >= 0.0 && gen->wall_density <= 1.0)) return fail(ANTSRL_E_INVALID, "bad wall_density");
+    if (gen->wall_kind == ANTSRL_WALLS_BERNOULLI) {
+        if (!(gen->wall_density >= 0.0 && gen->wall_density <= 1.0)) return fail(ANTSRL_E_INVALID, "bad wall_density");
+    } else if (gen->wall_kind == ANTSRL_WALLS_PERLIN) {
+        if (!(gen->wall_density >= -1.0 && gen->wall_density <= 1.0) || gen->perlin_octaves < 1 || gen->perlin_octaves > 8 ||
+            !(gen->perlin_scale > 0.0) || !(gen->perlin_persistence > 0.0) || !(gen->perlin_lacunarity > 0.0))
+            return fail(ANTSRL_E_INVALID, "bad Perlin wall parameters (density in [-1, 1], 1..8 octaves, positive "
+                                          "scale / persistence / lacunarity)");
+    } else {
+        return fail(ANTSRL_E_INVALID, "bad wall_kind %d", gen->wall_kind);
+    }
     h->gen = *gen;
     h->has_gen = true;
     return do_generate(h, episode_seed, (hipStream_t)stream);

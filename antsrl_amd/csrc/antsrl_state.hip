@@ -82,7 +82,7 @@ __global__ void k_reset_grids(const KP p, const float *__restrict__ food, const 
 // Draw `idx` of stream `tag` of environment `env`; the oracle (oracle_gen_u01) is bit-identical.
 #define GEN_SALT 0x6A09E667F3BCC909ULL
 enum { GEN_ANTHILL = 0, GEN_WALLS = 1, GEN_FOOD = 2, GEN_ROCKS = 3, GEN_ANT_ANGLE = 4, GEN_ANT_DIST = 5,
-       GEN_ANT_THETA = 6, GEN_ANT_SEED = 7 };
+       GEN_ANT_THETA = 6, GEN_ANT_SEED = 7, GEN_WALL_OFFSET = 8 };
 __device__ __forceinline__ double gen_u01(uint64_t seed, uint32_t env, uint32_t tag, uint32_t idx)
 {
     return jitter_u01(seed ^ GEN_SALT, env, tag, idx);
@@ -117,6 +117,64 @@ __global__ void k_gen_env(const KP p, const AntsGen g, const uint64_t seed)
     }
 }
 
+// ---- PerlinGenerator (generator/map_generators.py:9-25 over utils.py:7-17): 2-D improved Perlin noise
+// (Perlin 2002: permutation table, quintic fade, 16 gradient directions; octaves summed as total / max),
+// float32 like the `noise` package the reference calls.  antsrl_amd/generator.py (perlin_noise) and the
+// oracle hold the same arithmetic; all three agree bit for bit (-ffp-contract=off).
+__device__ const uint8_t PERLIN_PERM[256] = {
+    151, 160, 137, 91, 90, 15, 131, 13, 201, 95, 96, 53, 194, 233, 7, 225, 140, 36, 103, 30, 69, 142, 8, 99, 37, 240,
+    21, 10, 23, 190, 6, 148, 247, 120, 234, 75, 0, 26, 197, 62, 94, 252, 219, 203, 117, 35, 11, 32, 57, 177, 33, 88,
+    237, 149, 56, 87, 174, 20, 125, 136, 171, 168, 68, 175, 74, 165, 71, 134, 139, 48, 27, 166, 77, 146, 158, 231, 83,
+    111, 229, 122, 60, 211, 133, 230, 220, 105, 92, 41, 55, 46, 245, 40, 244, 102, 143, 54, 65, 25, 63, 161, 1, 216,
+    80, 73, 209, 76, 132, 187, 208, 89, 18, 169, 200, 196, 135, 130, 116, 188, 159, 86, 164, 100, 109, 198, 173, 186,
+    3, 64, 52, 217, 226, 250, 124, 123, 5, 202, 38, 147, 118, 126, 255, 82, 85, 212, 207, 206, 59, 227, 47, 16, 58, 17,
+    182, 189, 28, 42, 223, 183, 170, 213, 119, 248, 152, 2, 44, 154, 163, 70, 221, 153, 101, 155, 167, 43, 172, 9, 129,
+    22, 39, 253, 19, 98, 108, 110, 79, 113, 224, 232, 178, 185, 112, 104, 218, 246, 97, 228, 251, 34, 242, 193, 238,
+    210, 144, 12, 191, 179, 162, 241, 81, 51, 145, 235, 249, 14, 239, 107, 49, 192, 214, 31, 181, 199, 106, 157, 184,
+    84, 204, 176, 115, 121, 50, 45, 127, 4, 150, 254, 138, 236, 205, 93, 222, 114, 67, 29, 24, 72, 243, 141, 128, 195,
+    78, 66, 215, 61, 156, 180};
+__device__ const int8_t PERLIN_GRAD[16][2] = {{1, 1}, {-1, 1}, {1, -1}, {-1, -1}, {1, 0}, {-1, 0}, {1, 0}, {-1, 0},
+                                              {0, 1}, {0, -1}, {0, 1}, {0, -1}, {1, 0}, {-1, 0}, {0, -1}, {0, 1}};
+
+__device__ __forceinline__ float perlin_grad(int hash, float gx, float gy)
+{
+    const int h = PERLIN_PERM[hash & 255] & 15;
+    return gx * (float)PERLIN_GRAD[h][0] + gy * (float)PERLIN_GRAD[h][1];
+}
+__device__ __forceinline__ float perlin_lerp(float t, float a, float b) { return a + t * (b - a); }
+
+__device__ float perlin_noise2(float x, float y, float rx, float ry)
+{
+    long i = (long)floorf(fmodf(x, rx)), j = (long)floorf(fmodf(y, ry));
+    long ii = (long)fmodf((float)(i + 1), rx), jj = (long)fmodf((float)(j + 1), ry);
+    i &= 255; j &= 255; ii &= 255; jj &= 255;
+    x = x - floorf(x);
+    y = y - floorf(y);
+    const float fx = x * x * x * (x * (x * 6.0f - 15.0f) + 10.0f);
+    const float fy = y * y * y * (y * (y * 6.0f - 15.0f) + 10.0f);
+    const int A = PERLIN_PERM[i], B = PERLIN_PERM[ii];
+    const int AA = PERLIN_PERM[(A + j) & 255], AB = PERLIN_PERM[(A + jj) & 255];
+    const int BA = PERLIN_PERM[(B + j) & 255], BB = PERLIN_PERM[(B + jj) & 255];
+    return perlin_lerp(fy, perlin_lerp(fx, perlin_grad(AA, x, y), perlin_grad(BA, x - 1.0f, y)),
+                       perlin_lerp(fx, perlin_grad(AB, x, y - 1.0f), perlin_grad(BB, x - 1.0f, y - 1.0f)));
+}
+
+// pnoise2((cx + ox) / scale, (cy + oy) / scale, octaves, persistence, lacunarity), utils.py:11-16
+__device__ double perlin_at(long cx, long cy, long ox, long oy, const AntsGen &g)
+{
+    const float x = (float)((double)(cx + ox) / g.perlin_scale), y = (float)((double)(cy + oy) / g.perlin_scale);
+    if (g.perlin_octaves == 1) return (double)perlin_noise2(x, y, 1024.0f, 1024.0f);
+    float freq = 1.0f, amp = 1.0f, mx = 0.0f, total = 0.0f;
+    for (int o = 0; o < g.perlin_octaves; ++o) {
+        const float rep = (float)(1024.0 * (double)freq);
+        total = total + perlin_noise2(x * freq, y * freq, rep, rep) * amp;
+        mx = mx + amp;
+        freq = freq * (float)g.perlin_lacunarity;
+        amp = amp * (float)g.perlin_persistence;
+    }
+    return (double)(total / mx);
+}
+
 // per 32-cell word: anthill area (anthill.py:28-33), walls cleared on it (:66-67), food discs zeroed
 // on walls (:71-72), empty pheromone and explored map
 __global__ void k_gen_cells(const KP p, const AntsGen g, const uint64_t seed)
@@ -127,13 +185,18 @@ __global__ void k_gen_cells(const KP p, const AntsGen g, const uint64_t seed)
         const size_t e = i / p.words, w = i - e * p.words;
         const long ax = p.s.anthill_xyr[3 * e + 0], ay = p.s.anthill_xyr[3 * e + 1], ar = p.s.anthill_xyr[3 * e + 2];
         const int32_t *discs = p.s.gen_discs + e * ANTSRL_MAX_FOOD_DISCS * 3;
+        // PerlinGenerator.generate: random.randint(-10000, 10000) twice (map_generators.py:19-20)
+        const long pox = (long)(gen_u01(seed, (uint32_t)e, GEN_WALL_OFFSET, 0) * 20001.0) - 10000;
+        const long poy = (long)(gen_u01(seed, (uint32_t)e, GEN_WALL_OFFSET, 1) * 20001.0) - 10000;
         uint32_t wb = 0, ab = 0;
         for (int b = 0; b < 32; ++b) {
             const size_t cell = w * 32 + b;
             if (cell >= G) break;
             const long x = (long)(cell / p.H), y = (long)(cell % p.H);
             const bool area = ar >= 0 && (ax - x) * (ax - x) + (ay - y) * (ay - y) <= ar * ar;
-            const bool wall = !area && gen_u01(seed, (uint32_t)e, GEN_WALLS, (uint32_t)cell) < g.wall_density;
+            const bool wall = !area && (g.wall_kind == ANTSRL_WALLS_PERLIN
+                                            ? perlin_at(x, y, pox, poy, g) > g.wall_density
+                                            : gen_u01(seed, (uint32_t)e, GEN_WALLS, (uint32_t)cell) < g.wall_density);
             bool fd = false;
             for (int d = 0; d < g.n_food_discs; ++d) {
                 const long rad = discs[3 * d], dx = discs[3 * d + 1] - x, dy = discs[3 * d + 2] - y;

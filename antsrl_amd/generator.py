@@ -231,15 +231,26 @@ class EnvironmentGenerator:  # generator/environment_generator.py:19-106
 class DeviceEnvironmentGenerator(EnvironmentGenerator):
     """EnvironmentGenerator whose draws happen ON THE GPU (antsrl_generate): no
     O(W*H) Python loops (anthill.py:29-33, map_generators.py:42-46), no host arrays, no upload.
-    Walls are independent cells of the given density, food is `n_food_discs` discs of radius
-    food_rmin..food_rmax (CirclesGenerator's family, main.py:74).  Random streams are counter-based,
-    NOT the reference's MT19937: same distribution, different maps.  auto_reset=True regenerates
-    every env (seed+1, seed+2, ...) right after the update of the step that reported done."""
+    Walls are independent cells of the given density, or — walls_generator=PerlinGenerator(...), as in
+    main.py:75 — that generator's Perlin caves drawn on the device (its scale / density / octaves /
+    persistence / lacunarity; the same noise function as PerlinGenerator.generate on the host); food is
+    `n_food_discs` discs of radius food_rmin..food_rmax (CirclesGenerator's family, main.py:74).  Random
+    streams are counter-based, NOT the reference's MT19937: same distribution, different maps.
+    auto_reset=True regenerates every env (seed+1, seed+2, ...) right after the update of the step that
+    reported done."""
 
     def __init__(self, w, h, n_ants, n_pheromones, n_rocks, max_steps, seed=0, n_envs=1, wall_density=0.05,
-                 n_food_discs=20, food_rmin=5, food_rmax=10, auto_reset=False):
-        super().__init__(w, h, n_ants, n_pheromones, n_rocks, None, None, max_steps, seed=seed, n_envs=n_envs)
-        self.gen = cm.make_gen(wall_density, n_food_discs, food_rmin, food_rmax, auto_reset)
+                 n_food_discs=20, food_rmin=5, food_rmax=10, auto_reset=False, walls_generator=None):
+        super().__init__(w, h, n_ants, n_pheromones, n_rocks, None, walls_generator, max_steps, seed=seed, n_envs=n_envs)
+        if walls_generator is None:
+            self.gen = cm.make_gen(wall_density, n_food_discs, food_rmin, food_rmax, auto_reset)
+        elif isinstance(walls_generator, PerlinGenerator):
+            g = walls_generator
+            self.gen = cm.make_gen(g.density, n_food_discs, food_rmin, food_rmax, auto_reset, walls="perlin",
+                                   perlin_scale=g.scale, perlin_octaves=g.octaves, perlin_persistence=g.persistence,
+                                   perlin_lacunarity=g.lacunarity)
+        else:
+            raise TypeError("the device generator draws Bernoulli walls (walls_generator=None) or a PerlinGenerator's")
 
     def generate(self, rl_api: RLApi) -> Environment:
         env = Environment(self.w, self.h, self.max_steps)

@@ -148,12 +148,23 @@ typedef struct AntsInit {
  * EnvironmentGenerator.__init__ / CirclesGenerator (generator/environment_generator.py:20-46,
  * generator/map_generators.py:28-33, main.py:70-77) that are not already in AntsCfg. */
 #define ANTSRL_MAX_FOOD_DISCS 64
+#define ANTSRL_WALLS_BERNOULLI 0 /* independent wall cells with probability wall_density */
+#define ANTSRL_WALLS_PERLIN 1    /* PerlinGenerator (generator/map_generators.py:9-25, main.py:75):
+                                    wall = pnoise2((x + ox) / scale, (y + oy) / scale, octaves, persistence,
+                                    lacunarity) > wall_density, per-env offsets ox, oy uniform in
+                                    [-10000, 10000]; improved Perlin noise restated from the published
+                                    algorithm in float32 (the `noise` package is absent: unpinned) */
 typedef struct AntsGen {
-    double wall_density;   /* independent wall cells (stand-in for PerlinGenerator: needs `noise`) */
+    double wall_density;   /* Bernoulli: probability of a wall cell; Perlin: PerlinGenerator.density (threshold) */
     int32_t n_food_discs;  /* CirclesGenerator.n_circles, main.py:74 uses 20 (<= ANTSRL_MAX_FOOD_DISCS) */
     int32_t food_rmin, food_rmax; /* CirclesGenerator min/max radius, main.py:74 uses 5, 10 */
     int32_t auto_reset;    /* 1: antsrl_step_update regenerates every env right after the update of
                               the step that reported done (RL_api.py:200), with the next episode seed */
+    int32_t wall_kind;     /* ANTSRL_WALLS_* */
+    int32_t perlin_octaves;      /* PerlinGenerator defaults: 2 (1..8) */
+    double perlin_scale;         /* 22.0 */
+    double perlin_persistence;   /* 0.5 */
+    double perlin_lacunarity;    /* 2.0 */
 } AntsGen;
 
 typedef struct AntsHandle AntsHandle;

@@ -82,10 +82,79 @@ double oracle_jitter_u01(uint64_t seed, uint32_t env, uint32_t timestep, uint32_
  * counter-based generator instead of Python's MT19937 streams. */
 #define GEN_SALT 0x6A09E667F3BCC909ULL
 enum { GEN_ANTHILL = 0, GEN_WALLS = 1, GEN_FOOD = 2, GEN_ROCKS = 3, GEN_ANT_ANGLE = 4, GEN_ANT_DIST = 5,
-       GEN_ANT_THETA = 6, GEN_ANT_SEED = 7 };
+       GEN_ANT_THETA = 6, GEN_ANT_SEED = 7, GEN_WALL_OFFSET = 8 };
 static double gen_u01(uint64_t seed, uint32_t env, uint32_t tag, uint32_t idx)
 {
     return oracle_jitter_u01(seed ^ GEN_SALT, env, tag, idx);
+}
+
+/* ---- Perlin walls (generator/map_generators.py:9-25 -> utils.py:7-17 -> noise.pnoise2) ----
+ * The `noise` package is a third-party dependency that is neither installed nor under /root/reference
+ * (no pinned version: the reference has no requirements file).  Restated from the published algorithm
+ * (K. Perlin, "Improving Noise", 2002: reference permutation, fade 6t^5 - 15t^4 + 10t^3, gradient from
+ * the low 4 bits of the hash over 16 directions; fractal sum returned as total / sum of amplitudes), in
+ * float32.  PARITY UNPINNED against the package; pinned against antsrl_amd/generator.py::perlin_noise
+ * (numpy, tests/test_generator.py) and the device generator (tests/test_gpu_generate.py). */
+static const unsigned char PERLIN_P[256] = {
+    151, 160, 137, 91, 90, 15, 131, 13, 201, 95, 96, 53, 194, 233, 7, 225, 140, 36, 103, 30, 69, 142, 8, 99, 37, 240,
+    21, 10, 23, 190, 6, 148, 247, 120, 234, 75, 0, 26, 197, 62, 94, 252, 219, 203, 117, 35, 11, 32, 57, 177, 33, 88,
+    237, 149, 56, 87, 174, 20, 125, 136, 171, 168, 68, 175, 74, 165, 71, 134, 139, 48, 27, 166, 77, 146, 158, 231, 83,
+    111, 229, 122, 60, 211, 133, 230, 220, 105, 92, 41, 55, 46, 245, 40, 244, 102, 143, 54, 65, 25, 63, 161, 1, 216,
+    80, 73, 209, 76, 132, 187, 208, 89, 18, 169, 200, 196, 135, 130, 116, 188, 159, 86, 164, 100, 109, 198, 173, 186,
+    3, 64, 52, 217, 226, 250, 124, 123, 5, 202, 38, 147, 118, 126, 255, 82, 85, 212, 207, 206, 59, 227, 47, 16, 58, 17,
+    182, 189, 28, 42, 223, 183, 170, 213, 119, 248, 152, 2, 44, 154, 163, 70, 221, 153, 101, 155, 167, 43, 172, 9, 129,
+    22, 39, 253, 19, 98, 108, 110, 79, 113, 224, 232, 178, 185, 112, 104, 218, 246, 97, 228, 251, 34, 242, 193, 238,
+    210, 144, 12, 191, 179, 162, 241, 81, 51, 145, 235, 249, 14, 239, 107, 49, 192, 214, 31, 181, 199, 106, 157, 184,
+    84, 204, 176, 115, 121, 50, 45, 127, 4, 150, 254, 138, 236, 205, 93, 222, 114, 67, 29, 24, 72, 243, 141, 128, 195,
+    78, 66, 215, 61, 156, 180};
+static int perlin_p(long k) { return PERLIN_P[k & 255]; } /* the doubled table of the classic code */
+
+static float perlin_dot(int corner_hash, float dx, float dy)
+{
+    static const float dir[16][2] = {{1, 1}, {-1, 1}, {1, -1}, {-1, -1}, {1, 0}, {-1, 0}, {1, 0}, {-1, 0},
+                                     {0, 1}, {0, -1}, {0, 1}, {0, -1}, {1, 0}, {-1, 0}, {0, -1}, {0, 1}};
+    const float *d = dir[perlin_p(corner_hash) & 15];
+    return dx * d[0] + dy * d[1];
+}
+
+static float perlin_octave(float x, float y, float period_x, float period_y)
+{
+    long x0 = (long)floorf(fmodf(x, period_x)), y0 = (long)floorf(fmodf(y, period_y));
+    long x1 = (long)fmodf((float)(x0 + 1), period_x), y1 = (long)fmodf((float)(y0 + 1), period_y);
+    x0 &= 255; y0 &= 255; x1 &= 255; y1 &= 255;
+    const float tx = x - floorf(x), ty = y - floorf(y);
+    const float sx = tx * tx * tx * (tx * (tx * 6.0f - 15.0f) + 10.0f);
+    const float sy = ty * ty * ty * (ty * (ty * 6.0f - 15.0f) + 10.0f);
+    const int h00 = perlin_p(perlin_p(x0) + y0), h01 = perlin_p(perlin_p(x0) + y1);
+    const int h10 = perlin_p(perlin_p(x1) + y0), h11 = perlin_p(perlin_p(x1) + y1);
+    const float n00 = perlin_dot(h00, tx, ty), n10 = perlin_dot(h10, tx - 1.0f, ty);
+    const float n01 = perlin_dot(h01, tx, ty - 1.0f), n11 = perlin_dot(h11, tx - 1.0f, ty - 1.0f);
+    const float bottom = n00 + sx * (n10 - n00), top = n01 + sx * (n11 - n01);
+    return bottom + sy * (top - bottom);
+}
+
+static double perlin_fractal(float x, float y, int octaves, float persistence, float lacunarity)
+{
+    if (octaves == 1) return (double)perlin_octave(x, y, 1024.0f, 1024.0f);
+    float freq = 1.0f, amp = 1.0f, norm = 0.0f, sum = 0.0f;
+    for (int o = 0; o < octaves; ++o) {
+        const float period = (float)(1024.0 * (double)freq);
+        sum = sum + perlin_octave(x * freq, y * freq, period, period) * amp;
+        norm = norm + amp;
+        freq = freq * lacunarity;
+        amp = amp * persistence;
+    }
+    return (double)(sum / norm);
+}
+
+/* utils.py:7-17: gen[i][j] = pnoise2((i + offset_x) / scale, (j + offset_y) / scale, ...) */
+void oracle_perlin_noise(int w, int h, long offset_x, long offset_y, double scale, int octaves, double persistence,
+                         double lacunarity, double *out)
+{
+    for (long i = 0; i < w; ++i)
+        for (long j = 0; j < h; ++j)
+            out[i * h + j] = perlin_fractal((float)((double)(i + offset_x) / scale), (float)((double)(j + offset_y) / scale),
+                                            octaves, (float)persistence, (float)lacunarity);
 }
 
 void oracle_generate_init(const AntsCfg *c, const AntsGen *g, uint64_t seed, double *ants_xyt, double *seed_out,
@@ -114,11 +183,20 @@ void oracle_generate_init(const AntsCfg *c, const AntsGen *g, uint64_t seed, dou
             discs[d][1] = (int)(gen_u01(seed, e, GEN_FOOD, 3 * d + 1) * (W - 2 * rad) + rad);
             discs[d][2] = (int)(gen_u01(seed, e, GEN_FOOD, 3 * d + 2) * (H - 2 * rad) + rad);
         }
+        /* PerlinGenerator.generate draws random.randint(-10000, 10000) twice, map_generators.py:19-20 */
+        const long pox = (long)(gen_u01(seed, e, GEN_WALL_OFFSET, 0) * 20001.0) - 10000;
+        const long poy = (long)(gen_u01(seed, e, GEN_WALL_OFFSET, 1) * 20001.0) - 10000;
         for (long x = 0; x < W; ++x)
             for (long y = 0; y < H; ++y) {
                 const size_t cell = (size_t)x * H + y;
                 const int area = ar >= 0 && (ax - x) * (ax - x) + (ay - y) * (ay - y) <= ar * ar;
-                const int wall = !area && gen_u01(seed, e, GEN_WALLS, (uint32_t)cell) < g->wall_density; /* :66-67 */
+                int wall;                                                                 /* :66-67 */
+                if (g->wall_kind == ANTSRL_WALLS_PERLIN)
+                    wall = !area && perlin_fractal((float)((double)(x + pox) / g->perlin_scale),
+                                                   (float)((double)(y + poy) / g->perlin_scale), g->perlin_octaves,
+                                                   (float)g->perlin_persistence, (float)g->perlin_lacunarity) > g->wall_density;
+                else
+                    wall = !area && gen_u01(seed, e, GEN_WALLS, (uint32_t)cell) < g->wall_density;
                 int fd = 0;
                 for (int d = 0; d < g->n_food_discs; ++d) {
                     const long dx = discs[d][1] - x, dy = discs[d][2] - y;

@@ -48,6 +48,9 @@ def lib():
         _lib = C.CDLL(_LIB_PATH)
         _lib.oracle_jitter_u01.restype = C.c_double
         _lib.oracle_jitter_u01.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32]
+        _lib.oracle_perlin_noise.restype = None
+        _lib.oracle_perlin_noise.argtypes = [C.c_int, C.c_int, C.c_long, C.c_long, C.c_double, C.c_int, C.c_double,
+                                             C.c_double, C.c_void_p]
         _lib.oracle_max_threads.restype = C.c_int
     return _lib
 
@@ -158,6 +161,14 @@ def generate_init(cfg: AntsCfg, gen, seed: int) -> Dict[str, np.ndarray]:
         out.pop("rocks")
     else:
         out["rocks"] = out["rocks"][:, :R]
+    return out
+
+
+def perlin_noise(w, h, offset_x, offset_y, scale=22.0, octaves=2, persistence=0.5, lacunarity=2.0) -> np.ndarray:
+    """oracle_perlin_noise: utils.py:7-17 on the oracle's restatement of the noise function."""
+    out = np.zeros((w, h))
+    lib().oracle_perlin_noise(w, h, int(offset_x), int(offset_y), float(scale), int(octaves), float(persistence),
+                              float(lacunarity), _p(out))
     return out
 
 

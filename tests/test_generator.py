@@ -108,6 +108,11 @@ def test_perlin_walls_generator():
     y = ((np.arange(30) - 7) / 22.0).astype(np.float32)[None, :] * np.ones((40, 1), np.float32)
     two = (_noise2(x, y, 1024.0, 1024.0) + 0.5 * _noise2(2 * x, 2 * y, 2048.0, 2048.0)) / 1.5
     np.testing.assert_allclose(perlin_noise(40, 30, 11, -7), two, atol=1e-6)
+    # the oracle's C restatement agrees bit for bit (the device generator is held to the oracle on the GPU)
+    from oracle import oracle
+    for (w, h, ox, oy, sc, oc, pe, la) in [(64, 48, -3456, 7890, 22.0, 2, 0.5, 2.0), (50, 50, 9999, -10000, 7.5, 3, 0.4, 2.5),
+                                            (40, 60, -17, 5, 22.0, 1, 0.5, 2.0), (33, 21, 1234, 4321, 3.0, 4, 0.7, 1.9)]:
+        np.testing.assert_array_equal(oracle.perlin_noise(w, h, ox, oy, sc, oc, pe, la), perlin_noise(w, h, ox, oy, sc, oc, pe, la))
     # the generator: two draws from the global `random` stream, boolean map, reproducible under a seed
     random.seed(12)
     a = PerlinGenerator(scale=22.0, density=0.3).generate(96, 64)

@@ -126,3 +126,75 @@ def test_generate_random_shapes_and_parameters(seed):
     o_obs, o_ast, o_rew, o_done = orc.step(rot, ph)
     np.testing.assert_array_equal(_cpu(rew), o_rew.astype(np.float32))
     np.testing.assert_array_equal(_cpu(obs)[..., [0, 3, 4, 5]], o_obs[..., [0, 3, 4, 5]])
+
+
+@pytest.mark.parametrize("case", range(6))
+def test_generate_perlin_walls(case):
+    """walls="perlin" (PerlinGenerator, main.py:75) on the device: every env's wall map equals the host
+    generator's noise field at that env's offsets, thresholded and cleared on the anthill area — bit for
+    bit (device float32 == numpy float32 == the oracle's C), for the reference's parameters and others."""
+    from antsrl_amd import config as cm
+    from antsrl_amd.batched import BatchedAntsEnv
+    from antsrl_amd.generator import perlin_noise
+    from oracle import oracle
+    rng = np.random.default_rng(900 + case)
+    E, N = int(rng.integers(1, 6)), int(rng.choice([8, 50]))
+    W, H = int(rng.integers(24, 200)), int(rng.integers(24, 200))
+    kw = [dict(), dict(perlin_scale=22.0, wall_density=0.3), dict(perlin_scale=9.5, perlin_octaves=3, wall_density=0.1),
+          dict(perlin_octaves=1, wall_density=0.0), dict(perlin_persistence=0.7, perlin_lacunarity=1.7, perlin_octaves=4,
+                                                         wall_density=-0.1), dict(wall_density=0.05)][case]
+    gen = cm.make_gen(walls="perlin", n_food_discs=6, food_rmin=2, food_rmax=5, **kw)
+    cfg = cm.make_cfg(E, N, W, H, deposit_strength=256.0)
+    env = BatchedAntsEnv(cfg)
+    seed = 77 + case
+    env.generate(gen, episode_seed=seed)
+    orc = _check_fresh_episode(env, cfg, gen, seed)          # device == oracle (walls, food, ants, ...)
+    walls = _cpu(env.read_state(cm.S_WALLS)).astype(bool)
+    area = _cpu(env.read_state(cm.S_ANTHILL_AREA)).astype(bool)
+    SALT = 0x6A09E667F3BCC909
+    for e in range(E):                                       # device == the host PerlinGenerator's field
+        ox = int(oracle.jitter_u01(seed ^ SALT, e, 8, 0) * 20001.0) - 10000
+        oy = int(oracle.jitter_u01(seed ^ SALT, e, 8, 1) * 20001.0) - 10000
+        assert -10000 <= ox <= 10000 and -10000 <= oy <= 10000
+        field = perlin_noise(W, H, ox, oy, gen.perlin_scale, gen.perlin_octaves, gen.perlin_persistence, gen.perlin_lacunarity)
+        np.testing.assert_array_equal(walls[e], (field > gen.wall_density) & ~area[e])
+    if E > 1:
+        assert not np.array_equal(walls[0], walls[1])       # per-env offsets
+    rot = rng.integers(-1, 2, (E, N), dtype=np.int8)
+    ph = rng.integers(0, 3, (E, N), dtype=np.int8)
+    obs, ast, rew, done = env.step_update(rot, ph)
+    o_obs, o_ast, o_rew, o_done = orc.step(rot, ph)
+    np.testing.assert_array_equal(_cpu(rew), o_rew.astype(np.float32))
+
+
+def test_generate_rejects_bad_wall_parameters():
+    from antsrl_amd import _lib, config as cm
+    from antsrl_amd.batched import BatchedAntsEnv
+    env = BatchedAntsEnv(cm.make_cfg(1, 4, 16, 16))
+    for bad in (dict(walls="perlin", perlin_octaves=0), dict(walls="perlin", perlin_scale=0.0),
+                dict(walls="perlin", wall_density=1.5), dict(wall_density=1.5)):
+        with pytest.raises(_lib.AntsrlError):
+            env.generate(cm.make_gen(**bad), episode_seed=1)
+    g = cm.make_gen()
+    g.wall_kind = 7
+    with pytest.raises(_lib.AntsrlError, match="wall_kind"):
+        env.generate(g, episode_seed=1)
+
+
+def test_device_generator_takes_the_reference_walls_generator():
+    """main.py:70-77 with the draws on the GPU: PerlinGenerator(scale=22.0, density=0.3) as the walls
+    generator of DeviceEnvironmentGenerator maps to the device's Perlin walls with the same parameters."""
+    from antsrl_amd import config as cm
+    from antsrl_amd.generator import DeviceEnvironmentGenerator, PerlinGenerator
+    from antsrl_amd.rl_api import ExplorationReward, RLApi
+    api = RLApi(ExplorationReward(), 1, 1, 40 / 180 * np.pi, 0.05, 0.5)
+    g = DeviceEnvironmentGenerator(96, 80, 50, 2, 0, max_steps=50, seed=9, n_envs=3,
+                                   walls_generator=PerlinGenerator(scale=22.0, density=0.3))
+    assert g.gen.wall_kind == cm.WALLS_PERLIN and g.gen.wall_density == 0.3 and g.gen.perlin_scale == 22.0
+    env = g.generate(api)
+    obs, ast, state = api.observation()
+    assert obs.shape == (150, 7, 7, 6)
+    walls = _cpu(api._backend.read_state(cm.S_WALLS))
+    assert walls.shape == (3, 96, 80) and 0 < walls.mean() < 0.3
+    with pytest.raises(TypeError):
+        DeviceEnvironmentGenerator(32, 32, 4, 2, 0, max_steps=5, walls_generator=object())
