@@ -788,6 +788,22 @@ static ActPlan plan_act(const KP &p)
     };
     static const int pin = getenv("ANTSRL_ACT_PLAN") ? atoi(getenv("ANTSRL_ACT_PLAN")) : -1;
     ActPlan pl{};
+    // A batch that leaves half the CUs without a workgroup (E <= CUs / 2) with at least 512 ants per env:
+    // one 1024-thread workgroup per env puts twice the waves on the env's perception (c3's envs at
+    // E = 128: k_act 0.052 -> 0.041 ms; at E = 256 it is 6 % slower, profiles/plan_small_e.sh).
+    static const int n_cus = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+            n = 256;
+        return n;
+    }();
+    if (pin < 0 && (long)p.E * 2 <= n_cus && p.N >= 512) {
+        for (bool st : {true, false}) {
+            pl.threads = 1024; pl.static_lds = st;
+            pl.lds = act_lds_bytes(p.N, p.PP, p.words, p.HT, p.K, 16, st, nullptr, nullptr, p.R);
+            if (pl.lds <= cap) return pl;
+        }
+    }
     int k = 0;
     for (const auto &c : cand) {
         pl.threads = c.threads;
