@@ -286,6 +286,47 @@ def test_full_bench_batch_long_horizon_vs_oracle(torch_mod):
     assert orc.anthill_food.sum() > 0 and (orc.holding > 0).any(), "the run should exercise pickup and delivery"
 
 
+def test_full_config4_shard_sampled_envs_vs_oracle(torch_mod):
+    """The FULL per-GPU shard of BASELINE config 4 (1024 envs x 1024 ants, 512x512, radius-3 diffusion:
+    explicit sweep kernel, two pheromone buffers, 1024-thread workgroups): three sampled environments
+    follow the oracle for three steps; pheromone grids within 1e-5."""
+    from antsrl_amd import config as cm
+    from antsrl_amd.batched import BatchedAntsEnv
+    from antsrl_amd.synth import random_actions, synth_init
+    from oracle.oracle import Oracle
+    ax = np.arange(-3, 4)
+    g = np.exp(-(ax[:, None] ** 2 + ax[None, :] ** 2) / 4.5)
+    g = g / g.sum() * (1 - 0.001)
+    E, N, steps, pick = 1024, 1024, 3, [0, 517, 1023]
+    cfg = cm.make_cfg(E, N, 512, 512, filt=g, deposit_strength=256.0)
+    cfg_s = cm.make_cfg(len(pick), N, 512, 512, filt=g, deposit_strength=256.0)
+    init = synth_init(cfg, seed=77)
+    orc = Oracle(cfg_s, {k: np.ascontiguousarray(v[pick]) for k, v in init.items()}, n_threads=3)
+    env = BatchedAntsEnv(cfg)
+    env.reset(init)
+    del init
+    rot, ph = random_actions(cfg, steps, seed=5)
+    rng = np.random.default_rng(41)
+    for t in range(steps):
+        jit = rng.random((E, N))  # injected draws: the built-in generator is keyed on the env's index in ITS batch
+        obs, ast, rew, done = env.step_update(rot[t], ph[t], jit)
+        o_obs, o_ast, o_rew, o_done = orc.step(rot[t][pick], ph[t][pick])
+        orc.update(jit[pick])
+        go = _cpu(obs[pick])
+        for j in range(len(pick)):
+            check_obs(cfg_s, go[j], o_obs[j], "config 4 step %d env %d" % (t, pick[j]))
+        np.testing.assert_array_equal(_cpu(rew[pick]), o_rew.astype(np.float32))
+    xyt = _cpu(env.read_state(cm.S_ANTS_XYT))
+    np.testing.assert_allclose(xyt[pick], orc.ants_xyt, rtol=0, atol=XY_ATOL)
+    assert np.isfinite(xyt).all() and xyt[..., :2].min() >= 0 and xyt[..., :2].max() < 512
+    phero = env.read_state(cm.S_PHERO)  # 2 GiB on the device; only the sampled envs come to the host
+    food = env.read_state(cm.S_FOOD)
+    for j, e in enumerate(pick):
+        ph_e = _cpu(phero[e])
+        assert phero_close(ph_e, orc.phero[j]).all() and ph_e.max() > 0
+        np.testing.assert_array_equal(_cpu(food[e]), orc.food[j])
+
+
 def test_config2_vs_oracle_injected_jitter(torch_mod):
     from antsrl_amd.config import make_cfg
     from antsrl_amd.synth import synth_init

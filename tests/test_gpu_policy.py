@@ -104,3 +104,49 @@ def test_policy_feature_sizes_and_row_counts(F):
         r16, p16 = pol.act(obs.to(torch.bfloat16).view(M, 1, 1, F), ast, logits=l16, env=henv)
         assert torch.allclose(l32, ref, rtol=0, atol=3e-3 * max(1.0, (F / 300) ** 0.5)), (F, M, float((l32 - ref).abs().max()))
         assert torch.equal(l32, l16) and torch.equal(r32, r16) and torch.equal(p32, p16), (F, M)
+
+
+def test_full_config5_shard_policy_in_loop():
+    """The FULL per-GPU shard of BASELINE config 5 (512 envs x 512 ants, 256x256, bfloat16 observations,
+    the linear DQN net evaluated in the loop): every step's logits against the PyTorch reference of the
+    same net over the whole batch, and three sampled environments against the oracle driven by the SAME
+    actions (the policy's), observation rounded to bfloat16."""
+    import torch
+    from antsrl_amd import config as cm
+    from antsrl_amd.batched import BatchedAntsEnv
+    from antsrl_amd.policy import LinearPolicy
+    from antsrl_amd.synth import synth_init
+    from oracle.oracle import Oracle
+    E, N, steps, pick = 512, 512, 4, [0, 255, 511]
+    cfg = cm.make_cfg(E, N, 256, 256, deposit_strength=256.0)
+    cfg_s = cm.make_cfg(len(pick), N, 256, 256, deposit_strength=256.0)
+    init = synth_init(cfg, seed=55)
+    orc = Oracle(cfg_s, {k: np.ascontiguousarray(v[pick]) for k, v in init.items()}, n_threads=3)
+    env = BatchedAntsEnv(cfg, obs_dtype=torch.bfloat16)
+    env.reset(init)
+    pol = LinearPolicy(cfg.pside * cfg.pside * cfg.n_channels, env.device, seed=5)
+    env.observe()
+    o_obs, o_ast, _ = orc.observe()
+    rng = np.random.default_rng(8)
+    logits = torch.empty((E * N, 6), dtype=torch.float32, device=env.device)
+    for t in range(steps):
+        # what the oracle saw is what the policy reads, rounded to bfloat16
+        got = env.obs[pick].to(torch.float32).cpu().numpy()
+        want = torch.from_numpy(o_obs.astype(np.float32)).to(torch.bfloat16).to(torch.float32).numpy()
+        ints = [0, 3, 4, 5]
+        np.testing.assert_array_equal(got[..., ints], want[..., ints])
+        assert np.abs(got[..., 1:3] - want[..., 1:3]).max() <= 2 ** -8  # one bf16 ulp below 1 on a 1e-5 difference
+        rot, ph = pol.act(env.obs, env.agent_state, logits=logits, env=env)
+        ref = pol.reference_logits(env.obs.to(torch.float32), env.agent_state)
+        assert torch.allclose(logits, ref, rtol=0, atol=3e-3), float((logits - ref).abs().max())
+        rot_h, ph_h = rot.cpu().numpy(), ph.cpu().numpy()
+        assert set(np.unique(rot_h)) <= {-1, 0, 1} and set(np.unique(ph_h)) <= {0, 1, 2}
+        jit = rng.random((E, N))
+        obs, ast, rew, done = env.step_update(rot, ph, jit)
+        o_obs, o_ast, o_rew, o_done = orc.step(rot_h[pick], ph_h[pick])
+        orc.update(jit[pick])
+        np.testing.assert_array_equal(rew[pick].cpu().numpy(), o_rew.astype(np.float32))
+        np.testing.assert_array_equal(ast[pick].cpu().numpy(), o_ast.astype(np.float32))
+    xyt = env.read_state(cm.S_ANTS_XYT).cpu().numpy()
+    np.testing.assert_allclose(xyt[pick], orc.ants_xyt, rtol=0, atol=1e-9)
+    np.testing.assert_array_equal(env.read_state(cm.S_FOOD).cpu().numpy()[pick], orc.food)
