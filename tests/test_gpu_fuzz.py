@@ -46,7 +46,12 @@ def _random_case(rng):
     return E, N, W, H, kw
 
 
-@pytest.mark.parametrize("seed", range(64))
+# a longer one-off campaign:  ANTSRL_FUZZ_BASE=64 ANTSRL_FUZZ_CASES=2000 python -m pytest tests/test_gpu_fuzz.py -m gpu -q
+import os
+_BASE, _CASES = int(os.environ.get("ANTSRL_FUZZ_BASE", "0")), int(os.environ.get("ANTSRL_FUZZ_CASES", "64"))
+
+
+@pytest.mark.parametrize("seed", range(_BASE, _BASE + _CASES))
 def test_random_configuration_vs_oracle(torch_mod, seed):
     from antsrl_amd import config as cm
     from antsrl_amd.batched import BatchedAntsEnv
