@@ -838,12 +838,15 @@ static hipError_t launch_act_t(const KP &p, const ActPlan &pl, const int8_t *rot
                                float *obs, float *agent_state, float *reward, uint8_t *done, int flags,
                                const double *jitter, int out_buf, hipStream_t st)
 {
-    static size_t attr_lds = 0; // dynamic-LDS opt-in is per kernel function, set once per size
-    if (pl.lds > attr_lds) {
+    // dynamic-LDS opt-in is per kernel function AND per device: set once per size on each device
+    static size_t attr_lds[ANTSRL_MAX_DEVICES] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= ANTSRL_MAX_DEVICES) return hipErrorInvalidDevice;
+    if (pl.lds > attr_lds[dev]) {
         hipError_t err = hipFuncSetAttribute((const void *)k_act<C, ST, LAYOUT, FAST, TPB, OBS16, ILV, BIG>,
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds);
         if (err != hipSuccess) return err;
-        attr_lds = pl.lds;
+        attr_lds[dev] = pl.lds;
     }
     hipLaunchKernelGGL((k_act<C, ST, LAYOUT, FAST, TPB, OBS16, ILV, BIG>), dim3(p.E), dim3(TPB), pl.lds, st, p, rot, ph, cur, obs,
                        agent_state, reward, done, flags, jitter, out_buf);

@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "../../include/antsrl.h"
+#define ANTSRL_MAX_DEVICES 64 // per-device launch bookkeeping (dynamic-LDS opt-in), as in antsrl_util.h
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
@@ -444,15 +445,17 @@ hipError_t antsrl_launch_policy(const float *obs, const float *agent_state, cons
             int blocks = (ntiles + 1) / 2;
             if (blocks > 256 * per_cu) blocks = 256 * per_cu;
             hipError_t e = hipSuccess;
+            int dev = 0;
+            if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= ANTSRL_MAX_DEVICES) return hipErrorInvalidDevice;
             if (obs_bf16) {
-                static size_t attr = 0;
-                if (lds > attr) { e = hipFuncSetAttribute((const void *)k_policy_flat<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = lds; }
+                static size_t attr[ANTSRL_MAX_DEVICES] = {}; // per kernel function and per device
+                if (lds > attr[dev]) { e = hipFuncSetAttribute((const void *)k_policy_flat<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr[dev] = lds; }
                 if (e != hipSuccess) return e;
                 hipLaunchKernelGGL(k_policy_flat<true>, dim3(blocks), dim3(128), lds, st, obs, agent_state, w1, b1, w2, b2, w3,
                                    b3, rot, ph, logits, M, F, ks, tile_elems);
             } else {
-                static size_t attr = 0;
-                if (lds > attr) { e = hipFuncSetAttribute((const void *)k_policy_flat<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = lds; }
+                static size_t attr[ANTSRL_MAX_DEVICES] = {}; // per kernel function and per device
+                if (lds > attr[dev]) { e = hipFuncSetAttribute((const void *)k_policy_flat<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr[dev] = lds; }
                 if (e != hipSuccess) return e;
                 hipLaunchKernelGGL(k_policy_flat<false>, dim3(blocks), dim3(128), lds, st, obs, agent_state, w1, b1, w2, b2, w3,
                                    b3, rot, ph, logits, M, F, ks, tile_elems);

@@ -117,6 +117,7 @@ __device__ __forceinline__ void wave_lds_sync()
 // device re-reads them within the step, and at 0.7 GB per launch a cached write stream evicts the
 // pheromone/food lines the perception gathers reuse and the ant state k_update reads next
 // (measured on c3, same box: k_act 0.340 -> 0.287 ms, k_update 0.051 -> 0.043 ms).
+#define ANTSRL_MAX_DEVICES 64 // per-device launch bookkeeping (dynamic-LDS opt-in)
 typedef float stream_f4 __attribute__((ext_vector_type(4)));
 typedef uint32_t stream_u4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void store_stream(float *dst, float v) { __builtin_nontemporal_store(v, dst); }

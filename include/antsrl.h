@@ -22,7 +22,7 @@
  *    failure on the calling thread;
  *  - a handle belongs to the device its workspace lives on (any number of handles per device), holds up
  *    to 65535 environments and is not thread-safe;
- *  - sizes: any grid (the per-env bit maps move from LDS to HBM scratch past ~600k cells), up to ~2500 ants
+ *  - sizes: any grid (the per-env bit maps move from LDS to HBM scratch past ~600k cells), up to ~2400 ants
  *    per env (per-ant frames are LDS-resident); antsrl_create() returns ANTSRL_E_UNSUPPORTED beyond that.
  */
 #ifndef ANTSRL_H
