@@ -280,13 +280,28 @@ hipError_t antsrl_launch_update(const KP &p, const double *jitter, int out_buf, 
     }
     const int threads = pick_update_threads(p.N);
     const size_t lds = update_lds_bytes(p, threads);
+    // more than 64 KiB of dynamic LDS (the hash of > 2048 ants) is an opt-in per kernel function and device
+#define UPDATE_GO(CC)                                                                                              \
+    {                                                                                                              \
+        static size_t seen[ANTSRL_MAX_DEVICES] = {};                                                               \
+        int dev = 0;                                                                                               \
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= ANTSRL_MAX_DEVICES) return hipErrorInvalidDevice; \
+        if (lds > 64 * 1024 && lds > seen[dev]) {                                                                  \
+            hipError_t err = hipFuncSetAttribute((const void *)k_update<CC>,                                       \
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);            \
+            if (err != hipSuccess) return err;                                                                     \
+            seen[dev] = lds;                                                                                       \
+        }                                                                                                          \
+        hipLaunchKernelGGL((k_update<CC>), dim3(p.E), dim3(threads), lds, st, p, jitter, out_buf);                 \
+    }
     switch (p.C) {
-    case 1: hipLaunchKernelGGL((k_update<1>), dim3(p.E), dim3(threads), lds, st, p, jitter, out_buf); break;
-    case 2: hipLaunchKernelGGL((k_update<2>), dim3(p.E), dim3(threads), lds, st, p, jitter, out_buf); break;
-    case 3: hipLaunchKernelGGL((k_update<3>), dim3(p.E), dim3(threads), lds, st, p, jitter, out_buf); break;
-    case 4: hipLaunchKernelGGL((k_update<4>), dim3(p.E), dim3(threads), lds, st, p, jitter, out_buf); break;
+    case 1: UPDATE_GO(1) break;
+    case 2: UPDATE_GO(2) break;
+    case 3: UPDATE_GO(3) break;
+    case 4: UPDATE_GO(4) break;
     default: return hipErrorInvalidValue;
     }
+#undef UPDATE_GO
     return hipGetLastError();
 }
 

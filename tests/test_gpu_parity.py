@@ -412,6 +412,7 @@ def test_large_and_ragged_ant_counts(torch_mod):
     from antsrl_amd.synth import synth_init
     for (E, N, W, H, kw, steps) in [
         (1, 1500, 64, 64, dict(n_rocks=2, deposit_strength=256.0), 5),
+        (1, 2400, 96, 96, dict(n_rocks=2, deposit_strength=256.0), 3),  # the most ants a workgroup's LDS holds
         (2, 1023, 96, 80, dict(n_rocks=3, deposit_strength=256.0), 5),
         (2, 300, 64, 64, dict(perception_radius=5, mask=None), 4),
     ]:
