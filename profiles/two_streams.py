@@ -23,10 +23,17 @@ def run(S, order="step"):
                      torch.randint(0, 3, (8, Es, N), generator=g, device=dev, dtype=torch.int8)))
         envs.append(env); streams.append(torch.cuda.Stream(dev))
     torch.cuda.synchronize()
+    main = torch.cuda.current_stream(dev)
     def step(t):
+        if order == "join":  # fork from / join into ONE caller stream every step: no overlap across steps
+            ev = torch.cuda.Event(); ev.record(main)
         for s in range(S):
             with torch.cuda.stream(streams[s]):
+                if order == "join":
+                    streams[s].wait_event(ev)
                 envs[s].step_update(acts[s][0][t % 8], acts[s][1][t % 8], None)
+                if order == "join":
+                    e2 = torch.cuda.Event(); e2.record(streams[s]); main.wait_event(e2)
     for t in range(WU): step(t)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -35,6 +42,7 @@ def run(S, order="step"):
     return (time.perf_counter() - t0) / K * 1e3
 
 for rep in range(2):
-    for S in (1, 4, 8, 16):
-        ms = run(S)
-        print("S=%d handles x %d envs: %.4f ms per step of all 1024 envs  (%.3g ant-steps/s)" % (S, E // S, ms, E * N / ms * 1e3))
+    for S, order in ((1, "step"), (4, "step"), (4, "join"), (2, "join"), (8, "step")):
+        ms = run(S, order)
+        print("S=%d handles x %d envs%s: %.4f ms per step of all 1024 envs  (%.3g ant-steps/s)" % (
+            S, E // S, " (fork/join on one stream every step)" if order == "join" else "", ms, E * N / ms * 1e3))
