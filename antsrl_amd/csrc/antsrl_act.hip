@@ -372,6 +372,16 @@ k_act(const KP p, const int8_t *__restrict__ rotation, const int8_t *__restrict_
         const CellOff of = L.off[q];
         const bool mask_q = L.t_mask[q] != 0;
         const uint32_t qK = (uint32_t)q * K;
+        // Lanes whose gathered value is never used (masked cells and the lanes past the perception that
+        // duplicate a masked last cell: 27 of 64 with the reference's mask) gather what the first needed lane
+        // gathers.  The CU's texture-address path
+        // works through a scattered gather at about one distinct cache line per clock — it, not HBM, paces
+        // the perception loop (49 + 86 clocks per ant for the gather and the row's stores) — and lanes on
+        // a line that is fetched anyway cost nothing (measured: k_act -4 %; within the quad only: -3.4 %).
+        // (Lanes past the perception are duplicates of its last cell, q = PP - 1: they stage the same values
+        // into the same slots, so they keep that cell's address whenever it is a needed one.)
+        const unsigned long long need_mask = __ballot(mask_q);
+        const int src_lane = mask_q ? lane : (need_mask ? __builtin_ctzll(need_mask) : 0);
         // Two register sets (current / prefetched group); plain arrays with compile-time indices only,
         // so they stay in VGPRs (a struct passed by reference ends up in scratch).
 #define ACT_FETCH(G0, CELL, IXV, IYV, PVV, FDV)                                                          \
@@ -397,7 +407,7 @@ k_act(const KP p, const int8_t *__restrict__ rotation, const int8_t *__restrict_
         /* unconditional gathers (masked cells too: in bounds, discarded) */                             \
         _Pragma("unroll") for (int u = 0; u < ACT_UNROLL; ++u)                                           \
         {                                                                                                \
-            const uint32_t gc_ = CELL[u];                                                                \
+            const uint32_t gc_ = (uint32_t)__shfl((int)CELL[u], src_lane); /* (CELL keeps the lane's own cell) */ \
             if (ILV) { /* one {p0, p1, food, pad} record per cell: a single 16-byte gather */            \
                 const float4 t = *reinterpret_cast<const float4 *>(ph + (size_t)gc_ * 4);                \
                 PVV[u][0] = t.x; PVV[u][C - 1] = t.y; FDV[u] = t.z;                                      \
