@@ -135,3 +135,27 @@ def test_random_configuration_fused_calls_and_standalone_observation(torch_mod, 
     np.testing.assert_allclose(_cpu(env.read_state(cm.S_ANTS_XYT)), orc.ants_xyt, rtol=0, atol=1e-9)
     np.testing.assert_array_equal(_cpu(env.read_state(cm.S_FOOD)), orc.food)
     np.testing.assert_array_equal(_cpu(env.read_state(cm.S_ANTHILL_FOOD)), orc.anthill_food)
+
+
+@pytest.mark.parametrize("seed", range(200, 208))
+def test_random_configuration_on_grids_past_the_lds_limit(torch_mod, seed):
+    """The random configurations on grids of 0.7–1.2 M cells: presence / explored maps in HBM scratch
+    (k_act<..., BIG>), every reward kind, masks, channel lists, rocks, both pheromone modes at radius 0."""
+    from antsrl_amd import config as cm
+    from antsrl_amd.synth import synth_init
+    rng = np.random.default_rng(3000 + seed)
+    E, N, W, H, kw = _random_case(rng)
+    E, N = 1, int(rng.choice([1, 40, 130, 600]))
+    W, H = int(rng.integers(700, 1100)), int(rng.integers(900, 1100))
+    kw["n_phero"] = 2
+    if kw["channels"] is not None:
+        kw["channels"] = [(k, a % 2) for k, a in kw["channels"]]
+    if np.asarray(kw["filt"]).shape[0] > 1:
+        kw["filt"] = np.array([[0.999]])  # keep the oracle's stencil over a million cells out of the test's time
+    kw["perception_radius"] = min(kw["perception_radius"], 5)
+    if kw["mask"] is not None:
+        p = 2 * kw["perception_radius"] + 1
+        kw["mask"] = rng.random((p, p)) < 0.8
+    cfg = cm.make_cfg(E, N, W, H, **kw)
+    init = synth_init(cfg, seed=seed, n_food_discs=6, food_rmin=2, food_rmax=6, wall_density=0.05)
+    _compare_with_oracle(torch_mod, cfg, init, steps=4, seed=seed, jitter_mode="injected")
