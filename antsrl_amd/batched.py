@@ -230,12 +230,21 @@ class BatchedAntsEnv:
         return self.obs, self.agent_state, self.reward, self.done
 
     def set_timing_events(self, events) -> None:
-        """events: sequence of 4 raw hipEvent_t handles (ints) or None; see antsrl_set_timing_events."""
+        """events: sequence of config.TIMING_EVENTS raw hipEvent_t handles (ints) or None; see
+        antsrl_set_timing_events."""
         if events is None:
             _lib.check(self.lib.antsrl_set_timing_events(self._h, None), "set_timing_events")
         else:
-            arr = (C.c_void_p * 4)(*[C.c_void_p(int(e)) for e in events])
+            n = cfgmod.TIMING_EVENTS
+            assert len(events) == n, "antsrl_set_timing_events takes %d events" % n
+            arr = (C.c_void_p * n)(*[C.c_void_p(int(e)) for e in events])
             _lib.check(self.lib.antsrl_set_timing_events(self._h, arr), "set_timing_events")
+
+    def query(self, what: int) -> int:
+        """antsrl_query: what the handle resolved its configuration to (config.Q_*)."""
+        v = C.c_longlong()
+        _lib.check(self.lib.antsrl_query(self._h, int(what), C.byref(v)), "query")
+        return int(v.value)
 
     def set_activation(self, act, new_deposit_strength: float = 0.0) -> None:
         """Ants.activate_all_pheromones (ants.py:86-87)."""

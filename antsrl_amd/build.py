@@ -16,9 +16,13 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libantsrl_hip.so")
-SOURCES = ["antsrl_act.hip", "antsrl_update.hip", "antsrl_sweep.hip", "antsrl_state.hip", "antsrl_capi.hip",
-           "antsrl_policy.hip"]
-HEADERS = [os.path.join(CSRC, h) for h in ("antsrl_device.h", "antsrl_util.h", "antsrl_update_env.h")] + [
+#: the same sources with -DANTSRL_PROFILING: A/B selectors, ablation flags and the k_act phase trace exist in this
+#: library only (profiles/*.sh, tests/alt_paths.sh load it through ANTSRL_LIB); the product library has none
+PROF_LIB_PATH = os.path.join(LIB_DIR, "libantsrl_hip_prof.so")
+SOURCES = ["antsrl_act.hip", "antsrl_perceive.hip", "antsrl_update.hip", "antsrl_sweep.hip", "antsrl_state.hip",
+           "antsrl_capi.hip", "antsrl_policy.hip"]
+HEADERS = [os.path.join(CSRC, h) for h in ("antsrl_device.h", "antsrl_util.h", "antsrl_update_env.h",
+                                           "antsrl_flush.h")] + [
     os.path.join(HERE, "..", "include", "antsrl.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17",
          "-Wall", "-Wno-unused-function"]
@@ -31,24 +35,64 @@ def hipcc() -> str:
     raise RuntimeError("hipcc not found (needs the ROCm toolchain)")
 
 
-def is_stale() -> bool:
-    if not os.path.exists(LIB_PATH):
+def is_stale(path: str = LIB_PATH) -> bool:
+    if not os.path.exists(path):
         return True
-    t = os.path.getmtime(LIB_PATH)
+    t = os.path.getmtime(path)
     deps = [os.path.join(CSRC, s) for s in SOURCES] + HEADERS + [os.path.abspath(__file__)]
     return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _compile(out: str, extra, verbose: bool) -> None:
+    """One hipcc process per source (they are independent translation units), then one link."""
+    os.makedirs(LIB_DIR, exist_ok=True)
+    objdir = os.path.join(LIB_DIR, "obj_" + os.path.splitext(os.path.basename(out))[0])
+    os.makedirs(objdir, exist_ok=True)
+    flags = [f for f in FLAGS if f != "-shared"] + list(extra)
+    procs = []
+    for src in SOURCES:
+        obj = os.path.join(objdir, src.replace(".hip", ".o"))
+        cmd = [hipcc()] + flags + ["-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((subprocess.Popen(cmd), obj, cmd))
+    objs = []
+    for pr, obj, cmd in procs:
+        if pr.wait() != 0:
+            raise subprocess.CalledProcessError(pr.returncode, cmd)
+        objs.append(obj)
+    subprocess.check_call([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", out])
 
 
 def build_hip(force: bool = False, verbose: bool = False) -> str:
     if not force and not is_stale():
         return LIB_PATH
-    os.makedirs(LIB_DIR, exist_ok=True)
-    cmd = [hipcc()] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB_PATH]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    _compile(LIB_PATH, [], verbose)
     return LIB_PATH
 
 
+def build_prof(force: bool = False, verbose: bool = False) -> str:
+    """libantsrl_hip_prof.so: the profiling build (A/B selectors, ablations, phase trace)."""
+    if not force and not is_stale(PROF_LIB_PATH):
+        return PROF_LIB_PATH
+    _compile(PROF_LIB_PATH, ["-DANTSRL_PROFILING"], verbose)
+    return PROF_LIB_PATH
+
+
+def build_variant(name: str, defines, verbose: bool = False) -> str:
+    """lib/variants/<name>.so: the profiling build plus extra -D switches (compile-time ablations and A/B
+    variants for profiles/*.sh; loaded through ANTSRL_LIB)."""
+    out = os.path.join(LIB_DIR, "variants", name + ".so")
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    _compile(out, ["-DANTSRL_PROFILING"] + list(defines), verbose)
+    return out
+
+
 if __name__ == "__main__":
+    if "--variant" in sys.argv:  # python -m antsrl_amd.build --variant NAME -DFOO -DBAR=1
+        i = sys.argv.index("--variant")
+        print(build_variant(sys.argv[i + 1], [a for a in sys.argv[i + 2:] if a.startswith("-D")], verbose=True))
+        sys.exit(0)
     print(build_hip(force="--force" in sys.argv, verbose=True))
+    if "--prof" in sys.argv:
+        print(build_prof(force="--force" in sys.argv, verbose=True))

@@ -18,7 +18,7 @@ from typing import Optional, Sequence
 
 import numpy as np
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 MAX_CHANNELS = 16
 MAX_PSIDE = 15
 MAX_PCELLS = MAX_PSIDE * MAX_PSIDE
@@ -29,6 +29,8 @@ MAX_PHERO = 4
 CH_ANTS, CH_PHERO, CH_ANTHILL, CH_WALLS, CH_FOOD, CH_ROCKS = range(6)
 REWARD_NONE, REWARD_EXPLORATION, REWARD_FOOD, REWARD_ALL = range(4)
 PHERO_AUTO, PHERO_EXPLICIT_SWEEP = 0, 1
+TIMING_EVENTS = 5  # antsrl_set_timing_events
+Q_CELL_META, Q_SCALED_UNITS, Q_INTERLEAVED, Q_FILTER_SEPARABLE, Q_PERCEIVE_RUN = range(5)  # antsrl_query
 
 (S_ANTS_XYT, S_PREV_XY, S_HOLDING, S_MANDIBLES, S_ACTIVATION, S_PHERO, S_FOOD, S_EXPLORED,
  S_ANTHILL_FOOD, S_ROCK_CENTERS, S_TIMESTEP, S_REWARD_STATE, S_WALLS, S_ANTHILL_AREA,

@@ -3,8 +3,8 @@
 // gather, reward.  Host launchers at the end.  No MFMA: nothing on this path is a dense contraction.
 #include "antsrl_util.h"
 #include "antsrl_update_env.h"
+#include "antsrl_flush.h"
 
-struct __align__(16) AntFrame { double cx, cy, ct, st; }; // perception centre, cos/sin(theta + pi/2)
 struct __align__(16) CellOff { double px, py; };            // rotated-grid offsets, RL_api.py:92-93
 
 struct ActLds {
@@ -80,9 +80,11 @@ __host__ __device__ __forceinline__ size_t act_lds_bytes(int N, int PP, int word
 #define LAYOUT_DEFAULT 1       // [Ants, Phero0, Phero1, Anthill, Walls, Food]   (generator order)
 #define LAYOUT_DEFAULT_ROCKS 2 // ... + [CircleObstacles]
 
-// Profiling only (ANTSRL_ABLATE bit ACT_ABL_TRACE): per-workgroup phase timeline of k_act.  Slot k of
-// workgroup e = s_memrealtime (100 MHz) at: 0 entry, 1 after phase 2, 2 after phase 3, 3 exit;
-// slot 4 = HW_ID, slot 5 = XCC_ID, slot 6 after phase 0, slot 7 after phase 1.  Read back with antsrl_debug_read_act_trace.
+// Profiling build only (-DANTSRL_PROFILING, ANTSRL_ABLATE bit ACT_ABL_TRACE): per-workgroup phase timeline of
+// k_act.  Slot k of workgroup e = s_memrealtime (100 MHz) at: 0 entry, 1 after phase 2, 2 after phase 3,
+// 3 exit; slot 4 = HW_ID, slot 5 = XCC_ID, slot 6 after phase 0, slot 7 after phase 1.  Read back with
+// antsrl_debug_read_act_trace (exported by libantsrl_hip_prof.so only).
+#ifdef ANTSRL_PROFILING
 #define ACT_TRACE_SLOTS 8
 #define ACT_TRACE_MAX_WG 8192
 __device__ unsigned long long g_act_trace[ACT_TRACE_SLOTS * ACT_TRACE_MAX_WG];
@@ -105,6 +107,9 @@ extern "C" int antsrl_debug_read_act_trace(unsigned long long *dst, int n_wg)
     return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_act_trace), sizeof(unsigned long long) * ACT_TRACE_SLOTS * (size_t)n_wg)
                    == hipSuccess ? ANTSRL_OK : ANTSRL_E_DEVICE;
 }
+#else
+__device__ __forceinline__ void act_trace(int, int, int, int) {}
+#endif
 
 // FAST selects the software-pipelined perception loop (see phase 3); the two loops live in
 // separate instantiations on purpose: with both in one kernel the optimiser stops scalarising the
@@ -352,8 +357,12 @@ k_act(const KP p, const int8_t *__restrict__ rotation, const int8_t *__restrict_
     const float inv_max = 1.0f / (float)p.max_val;
     const float g_now = (float)p.g_now;                       // scaled mode: v = u * f0^S ...
     const float cut = p.scaled ? (float)p.threshold : 0.0f;   // ... and 0 below the 0.01 cut
+#ifdef ANTSRL_PROFILING
     const bool abl_gather = flags & ACT_ABL_NO_GATHER, abl_store = flags & ACT_ABL_NO_STORE;
-    const bool abl_explore = flags & ACT_ABL_NO_EXPLORE;
+    const bool abl_explore = flags & ACT_ABL_NO_EXPLORE, abl_items = flags & ACT_ABL_NO_ITEMS;
+#else
+    constexpr bool abl_gather = false, abl_store = false, abl_explore = false, abl_items = false;
+#endif
     const int npass = (PP + 63) >> 6;
     const uint32_t row = (uint32_t)PP * (uint32_t)K;            // floats per ant
     float *stage = L.stage + (size_t)wave * L.stage_stride;
@@ -518,19 +527,13 @@ k_act(const KP p, const int8_t *__restrict__ rotation, const int8_t *__restrict_
                 uint16_t *dst16 = reinterpret_cast<uint16_t *>(obs) + ((size_t)e * N + (size_t)i0) * row;
                 const uint32_t mis16 = (uint32_t)(((uintptr_t)dst16 >> 1) & 7);
                 uint16_t *st16 = reinterpret_cast<uint16_t *>(stage), *d_al = dst16 - mis16;
-                const uint32_t g_lo = (mis16 + 7) >> 3, g_hi = (mis16 + rowp) >> 3;
-                const uint32_t head = (g_hi - g_lo >= 72u) ? ((8u - (((uint32_t)((uintptr_t)d_al >> 4) + g_lo) & 7u)) & 7u) : 0u;
-                const uint32_t g1 = min(g_lo + head + (uint32_t)lane, g_hi - 1);
-                const uint32_t g2 = min((uint32_t)lane < head ? g_lo + (uint32_t)lane : g_lo + 64u + (uint32_t)lane, g_hi - 1);
-                const uint4 w1 = reinterpret_cast<const uint4 *>(st16)[g1];
-                const uint4 w2 = reinterpret_cast<const uint4 *>(st16)[g2];
-                const uint32_t hd16 = 8 * g_lo - mis16, tl16 = mis16 + rowp - 8 * g_hi;
-                const uint32_t fe16 = (uint32_t)lane < hd16 ? mis16 + lane
-                                      : ((uint32_t)lane - hd16 < tl16 ? 8 * g_hi + ((uint32_t)lane - hd16) : mis16);
-                const uint16_t we = st16[fe16];
-                store_stream(reinterpret_cast<uint4 *>(d_al) + g1, w1);
-                store_stream(reinterpret_cast<uint4 *>(d_al) + g2, w2);
-                store_stream(d_al + fe16, we);
+                const FlushPlanB16 f = flush_plan_b16((uint32_t)lane, mis16, rowp, (uint32_t)((uintptr_t)d_al >> 4) & 7u);
+                const uint4 w1 = reinterpret_cast<const uint4 *>(st16)[f.g1];
+                const uint4 w2 = reinterpret_cast<const uint4 *>(st16)[f.g2];
+                const uint16_t we = st16[f.fe];
+                store_stream(reinterpret_cast<uint4 *>(d_al) + f.g1, w1);
+                store_stream(reinterpret_cast<uint4 *>(d_al) + f.g2, w2);
+                store_stream(d_al + f.fe, we);
                 wave_lds_sync();
             }
             if (!OBS16) {
@@ -544,22 +547,15 @@ k_act(const KP p, const int8_t *__restrict__ rotation, const int8_t *__restrict_
                 float *dst = obs_env + (size_t)i0 * row;
                 const uint32_t mis = (uint32_t)(((uintptr_t)dst >> 2) & 3);
                 float *dst_al = dst - mis;
-                const uint32_t j_lo = (mis + 3) >> 2, j_hi = (mis + rowp) >> 2; // interior float4s [j_lo, j_hi)
-                const uint32_t head = (j_hi - j_lo >= 72u) ? ((8u - (((uint32_t)((uintptr_t)dst_al >> 4) + j_lo) & 7u)) & 7u) : 0u;
-                const uint32_t j1 = min(j_lo + head + (uint32_t)lane, j_hi - 1);
-                const uint32_t j2 = min(j_lo + head + 64u + (uint32_t)lane, j_hi - 1);
-                const uint32_t j3 = min((uint32_t)lane < head ? j_lo + (uint32_t)lane : j_lo + 128u + (uint32_t)lane, j_hi - 1);
-                const float4 v1 = reinterpret_cast<const float4 *>(stage)[j1];
-                const float4 v2 = reinterpret_cast<const float4 *>(stage)[j2];
-                const float4 v3 = reinterpret_cast<const float4 *>(stage)[j3];
-                const uint32_t hd = 4 * j_lo - mis, tl = mis + rowp - 4 * j_hi;
-                const uint32_t fe = (uint32_t)lane < hd ? mis + lane
-                                    : ((uint32_t)lane - hd < tl ? 4 * j_hi + ((uint32_t)lane - hd) : mis);
-                const float ve = stage[fe];
-                store_stream(reinterpret_cast<float4 *>(dst_al) + j1, v1);
-                store_stream(reinterpret_cast<float4 *>(dst_al) + j2, v2);
-                store_stream(reinterpret_cast<float4 *>(dst_al) + j3, v3);
-                store_stream(dst_al + fe, ve);
+                const FlushPlanF32 f = flush_plan_f32((uint32_t)lane, mis, rowp, (uint32_t)((uintptr_t)dst_al >> 4) & 7u);
+                const float4 v1 = reinterpret_cast<const float4 *>(stage)[f.j1];
+                const float4 v2 = reinterpret_cast<const float4 *>(stage)[f.j2];
+                const float4 v3 = reinterpret_cast<const float4 *>(stage)[f.j3];
+                const float ve = stage[f.fe];
+                store_stream(reinterpret_cast<float4 *>(dst_al) + f.j1, v1);
+                store_stream(reinterpret_cast<float4 *>(dst_al) + f.j2, v2);
+                store_stream(reinterpret_cast<float4 *>(dst_al) + f.j3, v3);
+                store_stream(dst_al + f.fe, ve);
                 wave_lds_sync();
             }
 #pragma unroll
@@ -575,7 +571,7 @@ k_act(const KP p, const int8_t *__restrict__ rotation, const int8_t *__restrict_
     // wave works on a single ant at a time (the second slot of the group stays empty).
     const int ustep = npass > 1 ? 1 : ACT_UNROLL;
     if (!FAST)
-    for (int i0 = wave * ustep; i0 < ((flags & ACT_ABL_NO_ITEMS) ? 0 : N); i0 += nwaves * ustep) {
+    for (int i0 = wave * ustep; i0 < (abl_items ? 0 : N); i0 += nwaves * ustep) {
         for (int pass = 0; pass < npass; ++pass) {
             const int q = pass * 64 + lane;
             const bool lane_on = q < PP;
@@ -788,7 +784,7 @@ struct ActPlan {
 // throughput either) and one 1024-thread workgroup (0.306-0.315 ms).  So: bitmaps in
 // LDS at 3 then 2 workgroups per CU, only then the global-bitmap plans, then one 1024-thread
 // workgroup, then 512 threads with the whole CU's LDS.
-// ANTSRL_ACT_PLAN=<n> pins candidate n (A/B runs).
+// ANTSRL_ACT_PLAN=<n> pins candidate n (A/B runs, profiling build only).
 static ActPlan plan_act(const KP &p)
 {
     const size_t cap = 160 * 1024;
@@ -796,7 +792,7 @@ static ActPlan plan_act(const KP &p)
         {512, true, cap / 3},  {512, true, cap / 2},  {512, false, cap / 3}, {512, false, cap / 2},
         {1024, true, cap},     {1024, false, cap},    {512, false, cap},
     };
-    static const int pin = getenv("ANTSRL_ACT_PLAN") ? atoi(getenv("ANTSRL_ACT_PLAN")) : -1;
+    static const int pin = PROF_ENV("ANTSRL_ACT_PLAN") ? atoi(PROF_ENV("ANTSRL_ACT_PLAN")) : -1;
     ActPlan pl{};
     // A batch that leaves half the CUs without a workgroup (E <= CUs / 2) with at least 512 ants per env:
     // one 1024-thread workgroup per env puts twice the waves on the env's perception (c3's envs at
@@ -899,7 +895,7 @@ static hipError_t launch_act_c(const KP &p, const int8_t *rot, const int8_t *ph,
         else { if (ilv) ACT_GOF(ST, LY, false, true); else ACT_GOF(ST, LY, false, false); }       \
     }
     const bool o16 = (flags & ACT_OBS_BF16) != 0, ilv = p.ps == 4 && p.fs == 4;
-    if (o16 && (!fast || C != 2)) return hipErrorNotSupported; // bfloat16 observations: pipelined loop only
+    if (o16 && (!fast || C != 2 || row < 16)) return hipErrorNotSupported; // bfloat16 observations: pipelined loop only
     if (pl.big) // generic loop, generic channel selection, 512 threads
         return launch_act_t<C, false, LAYOUT_GENERIC, false, 512, false, false, true>(p, pl, rot, ph, cur, obs, agent_state, reward,
                                                                                       done, flags, jitter, out_buf, st);

@@ -28,6 +28,15 @@ hipError_t antsrl_launch_read_state(const KP &p, int which, int cur, void *dst, 
 hipError_t antsrl_launch_generate(const KP &p, const AntsGen &g, uint64_t seed, hipStream_t st);
 hipError_t antsrl_launch_phero_wall_clear(const KP &p, hipStream_t st);
 hipError_t antsrl_launch_phero_renorm(const KP &p, hipStream_t st);
+// cell-meta path (antsrl_perceive.hip)
+bool antsrl_meta_supported(const KP &p);
+hipError_t antsrl_launch_move(const KP &p, const int8_t *rot, const int8_t *ph, uint8_t *done, int do_step, uint32_t seq,
+                              hipStream_t st);
+hipError_t antsrl_launch_perceive(const KP &p, int cur, float *obs, float *agent_state, float *reward, int flags,
+                                  uint32_t seq, hipStream_t st);
+hipError_t antsrl_launch_meta_rebase(const KP &p, hipStream_t st);
+int antsrl_perceive_run(const KP &p);
+hipError_t antsrl_launch_copy16(void *dst, const void *src, size_t bytes, hipStream_t st);
 
 struct AntsHandle {
     AntsCfg cfg;
@@ -44,8 +53,9 @@ struct AntsHandle {
     long long sweeps;      // scaled mode: updates since the units were last re-based
     bool obs_bf16;         // observation buffers are bfloat16 (antsrl_set_obs_format)
     bool need_wall_clear;  // scaled mode: initial grid may hold pheromone on wall cells
-    hipEvent_t ev[4];      // measurement hook (antsrl_set_timing_events)
+    hipEvent_t ev[ANTSRL_TIMING_EVENTS]; // measurement hook (antsrl_set_timing_events)
     bool ev_armed;
+    uint32_t obs_seq;      // cell-meta path: observations since the explored stamps were last re-based
 };
 
 static thread_local char g_err[512] = "";
@@ -117,7 +127,7 @@ static bool use_scaled(const AntsCfg *c)
 // 180-197 against 275 from HBM).  ANTSRL_NO_INTERLEAVE keeps the separate arrays (A/B).
 static bool use_interleaved(const AntsCfg *c)
 {
-    static const bool off = getenv("ANTSRL_NO_INTERLEAVE") != nullptr;
+    static const bool off = PROF_ENV("ANTSRL_NO_INTERLEAVE") != nullptr;
     return !off && use_scaled(c) && c->n_phero == 2;
 }
 
@@ -134,6 +144,8 @@ static size_t carve(const AntsCfg *c, DState *s, unsigned char *base)
         off = (off + bytes + 255) / 256 * 256;
         return ptr;
     };
+    KP kp;
+    fill_kp(c, &kp);
     DState d;
     d.x = (double *)take(8 * E * N); d.y = (double *)take(8 * E * N); d.theta = (double *)take(8 * E * N);
     d.prev_x = (double *)take(8 * E * N); d.prev_y = (double *)take(8 * E * N);
@@ -150,19 +162,16 @@ static size_t carve(const AntsCfg *c, DState *s, unsigned char *base)
     } else {
         d.phero[0] = (float *)take(4 * E * G * Cn);
         d.phero[1] = use_scaled(c) ? d.phero[0] : (float *)take(4 * E * G * Cn); // no ping-pong when scaled
-        d.food = (float *)take(4 * E * G);
+        d.food = (float *)take(4 * E * G * (size_t)kp.fs); // {food, META} records on the cell-meta path
     }
     d.walls_bits = (uint32_t *)take(4 * E * words); d.area_bits = (uint32_t *)take(4 * E * words);
     d.explored_bits = (uint32_t *)take(4 * E * words);
     d.big_pres = d.big_old = nullptr;
-    {
-        KP kp;
-        fill_kp(c, &kp);
-        if (antsrl_act_needs_hbm_maps(kp)) {
-            d.big_pres = (uint32_t *)take(4 * E * words);
-            d.big_old = (uint32_t *)take(4 * E * words);
-        }
+    if (!kp.meta && antsrl_act_needs_hbm_maps(kp)) {
+        d.big_pres = (uint32_t *)take(4 * E * words);
+        d.big_old = (uint32_t *)take(4 * E * words);
     }
+    d.primed_cur = kp.meta ? (uint8_t *)take(E) : nullptr;
     d.anthill_xyr = (int32_t *)take(4 * E * 3);
     d.anthill_food = (double *)take(8 * E);
     d.rock_cx = (double *)take(8 * E * (R ? R : 1)); d.rock_cy = (double *)take(8 * E * (R ? R : 1));
@@ -218,7 +227,7 @@ static void fill_kp(const AntsCfg *c, KP *p)
         // rounding, and unbiased like the hi + lo split of the full filter.
         const int S = 2 * c->filter_radius + 1;
         p->filter_sep = 0;
-        if (S > 1 && !getenv("ANTSRL_NO_SEPARABLE")) {
+        if (S > 1 && !PROF_ENV("ANTSRL_NO_SEPARABLE")) {
             int i0 = 0, j0 = 0;
             double big = 0.0;
             for (int a = 0; a < S; ++a)
@@ -246,6 +255,10 @@ static void fill_kp(const AntsCfg *c, KP *p)
     p->ps = use_interleaved(c) ? 4 : c->n_phero;
     p->fs = use_interleaved(c) ? 4 : 1;
     p->g_now = p->g_dep = p->inv_g_dep = 1.0;
+    // cell-meta path (k_move + k_perceive) for the reference's perception shapes; ANTSRL_LEGACY_ACT (profiling
+    // build only) keeps k_act for A/B runs
+    p->meta = (antsrl_meta_supported(*p) && !PROF_ENV("ANTSRL_LEGACY_ACT")) ? 1 : 0;
+    if (p->meta && p->fs == 1) p->fs = 2;
 }
 
 // f0^S for the next observation, f0^(S+1) for the next deposit
@@ -287,7 +300,8 @@ extern "C" int antsrl_create(const AntsCfg *cfg, void *workspace, size_t workspa
     h->has_gen = false; h->episode_seed = 0; h->host_timestep = 1; h->obs_bf16 = false;
     h->ws_bytes = need;
     h->ev_armed = false;
-    if (!antsrl_act_fits(h->p)) {
+    h->obs_seq = 0;
+    if (!h->p.meta && !antsrl_act_fits(h->p)) {
         delete h;
         return fail(ANTSRL_E_UNSUPPORTED,
                     "%d ants with a %dx%d perception need more than 160 KiB of LDS per workgroup "
@@ -311,7 +325,7 @@ extern "C" int antsrl_reset(AntsHandle *h, const AntsInit *init, void *stream)
     h->p.deposit_strength = h->cfg.deposit_strength;
     h->cur = 0; h->steps_since_update = 0; h->need_full_collect = true; h->is_reset = true;
     h->sweeps = 0; h->need_wall_clear = h->p.scaled && init->phero != nullptr;
-    h->host_timestep = 1;
+    h->host_timestep = 1; h->obs_seq = 0;
     set_decay(h);
     return ANTSRL_OK;
 }
@@ -322,7 +336,7 @@ static int do_generate(AntsHandle *h, uint64_t seed, hipStream_t st)
     if (e != hipSuccess) return hip_fail(e, "generate");
     h->p.deposit_strength = h->cfg.deposit_strength;
     h->cur = 0; h->steps_since_update = 0; h->need_full_collect = true; h->is_reset = true;
-    h->sweeps = 0; h->need_wall_clear = false; h->host_timestep = 1;
+    h->sweeps = 0; h->need_wall_clear = false; h->host_timestep = 1; h->obs_seq = 0;
     h->episode_seed = seed;
     set_decay(h);
     return ANTSRL_OK;
@@ -366,14 +380,42 @@ extern "C" int antsrl_set_obs_format(AntsHandle *h, int format)
 
 static int not_reset() { return fail(ANTSRL_E_INVALID, "antsrl_reset has not been called on this handle"); }
 
+// One observation on the cell-meta path: k_move (with the action phases when `stepping`) then k_perceive.
+static int meta_observe(AntsHandle *h, const int8_t *rot, const int8_t *ph, float *obs, float *agent_state,
+                        float *reward, uint8_t *done, bool stepping, hipStream_t st, bool timed)
+{
+    hipError_t e;
+    if (h->obs_seq >= META_NEVER - 2) { // explored stamps: re-base long before the counter can reach "never"
+        e = antsrl_launch_meta_rebase(h->p, st);
+        if (e != hipSuccess) return hip_fail(e, "explored-stamp rebase");
+        h->obs_seq = 0;
+    }
+    h->obs_seq++;
+    e = antsrl_launch_move(h->p, rot, ph, done, stepping ? 1 : 0, h->obs_seq, st);
+    if (e != hipSuccess) return hip_fail(e, "move");
+    if (timed) (void)hipEventRecord(h->ev[2], st);
+    e = antsrl_launch_perceive(h->p, h->cur, obs, agent_state, reward,
+                               (stepping ? ACT_STEP : 0) | (obs ? ACT_HAS_OBS : 0) | (obs && h->obs_bf16 ? ACT_OBS_BF16 : 0),
+                               h->obs_seq, st);
+    if (e != hipSuccess) return hip_fail(e, "perceive");
+    return ANTSRL_OK;
+}
+
 static int do_step(AntsHandle *h, const int8_t *rot, const int8_t *ph, float *obs, float *agent_state,
                    float *reward, uint8_t *done, hipStream_t st, bool fused_update = false,
-                   const double *jitter = nullptr)
+                   const double *jitter = nullptr, bool timed = false)
 {
     if (ph && h->p.C != 2) // Ants.activate_pheromone hard-codes two channels, ants.py:89-96
         return fail(ANTSRL_E_INVALID, "pheromone actions need exactly 2 pheromone channels (ants.py:89-96)");
     if (h->steps_since_update > 0) h->need_full_collect = true; // dirty-cell list would be overwritten
-    static const int ablate = getenv("ANTSRL_ABLATE") ? atoi(getenv("ANTSRL_ABLATE")) & ~7 : 0; // profiling only
+    if (h->p.meta) {
+        int rc = meta_observe(h, rot, ph, obs, agent_state, reward, done, true, st, timed);
+        if (rc) return rc;
+        h->steps_since_update++;
+        return ANTSRL_OK;
+    }
+    if (timed) (void)hipEventRecord(h->ev[2], st);
+    static const int ablate = PROF_ENV("ANTSRL_ABLATE") ? atoi(PROF_ENV("ANTSRL_ABLATE")) & ~15 : 0; // profiling build only
     hipError_t e = antsrl_launch_act(h->p, rot, ph, h->cur, obs, agent_state, reward, done,
                                      ACT_STEP | (obs ? ACT_HAS_OBS : 0) | (fused_update ? ACT_FUSED_UPDATE : 0) | ablate |
                                          (obs && h->obs_bf16 ? ACT_OBS_BF16 : 0),
@@ -437,6 +479,8 @@ extern "C" int antsrl_observe(AntsHandle *h, float *obs, float *agent_state, flo
 {
     if (!h) return fail(ANTSRL_E_INVALID, "NULL handle");
     if (!h->is_reset) return not_reset();
+    if (h->p.meta)
+        return meta_observe(h, nullptr, nullptr, obs, agent_state, reward, nullptr, false, (hipStream_t)stream, false);
     hipError_t e = antsrl_launch_act(h->p, nullptr, nullptr, h->cur, obs, agent_state, reward, nullptr,
                                      obs ? ACT_HAS_OBS | (h->obs_bf16 ? ACT_OBS_BF16 : 0) : 0, nullptr, 0,
                                      (hipStream_t)stream);
@@ -476,23 +520,46 @@ extern "C" int antsrl_step_update(AntsHandle *h, const int8_t *rotation, const i
     // the loop form of the update; the separate k_update_one has since become the faster kernel) — with
     // two workgroups per CU the update's latency-bound phases idle half the CU.  Opt-in
     // (ANTSRL_FUSE_UPDATE=1) for re-evaluation.
-    static const bool want_fuse = getenv("ANTSRL_FUSE_UPDATE") && atoi(getenv("ANTSRL_FUSE_UPDATE")) != 0;
-    const bool fuse = want_fuse && !(h->p.scaled && h->need_wall_clear);
+    static const bool want_fuse = PROF_ENV("ANTSRL_FUSE_UPDATE") && atoi(PROF_ENV("ANTSRL_FUSE_UPDATE")) != 0;
+    const bool fuse = want_fuse && !h->p.meta && !(h->p.scaled && h->need_wall_clear);
     if (fuse && h->p.scaled && h->p.g_dep < 1e-20) { // re-base before the launch (value-preserving)
         hipError_t e = antsrl_launch_phero_renorm(h->p, st);
         if (e != hipSuccess) return hip_fail(e, "pheromone renorm");
         h->sweeps = 0;
         set_decay(h);
     }
-    int rc = do_step(h, rotation, phero, obs, agent_state, reward, done, st, fuse, wall_jitter);
+    int rc = do_step(h, rotation, phero, obs, agent_state, reward, done, st, fuse, wall_jitter, timed);
     if (rc) return rc;
-    if (timed) (void)hipEventRecord(h->ev[2], st);
+    if (timed) (void)hipEventRecord(h->ev[3], st);
     const bool was_done = h->host_timestep == h->cfg.max_time; // RL_api.py:200, same for every env
     rc = do_update(h, wall_jitter, st, true, fuse);
-    if (timed) (void)hipEventRecord(h->ev[3], st);
+    if (timed) (void)hipEventRecord(h->ev[4], st);
     if (rc == ANTSRL_OK && was_done && h->has_gen && h->gen.auto_reset)
         rc = do_generate(h, h->episode_seed + 1, st); // next episode, like main.py:69-79 does per episode
     return rc;
+}
+
+extern "C" int antsrl_query(const AntsHandle *h, int what, long long *value)
+{
+    if (!h || !value) return fail(ANTSRL_E_INVALID, "NULL handle or value");
+    switch (what) {
+    case ANTSRL_Q_CELL_META: *value = h->p.meta; break;
+    case ANTSRL_Q_SCALED_UNITS: *value = h->p.scaled; break;
+    case ANTSRL_Q_INTERLEAVED: *value = h->p.ps == 4 && h->p.fs == 4; break;
+    case ANTSRL_Q_FILTER_SEPARABLE: *value = h->p.filter_sep; break;
+    case ANTSRL_Q_PERCEIVE_RUN: *value = h->p.meta ? antsrl_perceive_run(h->p) : 0; break;
+    default: return fail(ANTSRL_E_INVALID, "bad query selector %d", what);
+    }
+    return ANTSRL_OK;
+}
+
+extern "C" int antsrl_bench_copy(void *dst, const void *src, size_t bytes, void *stream)
+{
+    if (!dst || !src || (bytes & 15) || ((uintptr_t)dst & 15) || ((uintptr_t)src & 15))
+        return fail(ANTSRL_E_INVALID, "bench_copy: 16-byte aligned pointers and a multiple of 16 bytes");
+    hipError_t e = antsrl_launch_copy16(dst, src, bytes, (hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail(e, "bench_copy");
+    return ANTSRL_OK;
 }
 
 extern "C" int antsrl_set_timing_events(AntsHandle *h, void *const *events)
@@ -500,7 +567,7 @@ extern "C" int antsrl_set_timing_events(AntsHandle *h, void *const *events)
     if (!h) return fail(ANTSRL_E_INVALID, "NULL handle");
     h->ev_armed = events != nullptr;
     if (events)
-        for (int i = 0; i < 4; ++i) h->ev[i] = (hipEvent_t)events[i];
+        for (int i = 0; i < ANTSRL_TIMING_EVENTS; ++i) h->ev[i] = (hipEvent_t)events[i];
     return ANTSRL_OK;
 }
 

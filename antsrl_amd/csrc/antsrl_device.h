@@ -14,9 +14,42 @@
 //   walls / anthill area / explored map   bit-packed, 1 bit per cell: u32 [E][ceil(W*H/32)],
 //               bit index = x*H + y.  8 KiB per env at 256x256, so whole maps fit in LDS.
 //   rocks       float64 SoA [E][R]
+//
+// Cell-meta layout (KP::meta, the reference's perception shapes: antsrl_perceive.hip).  Every cell owns a
+// 32-bit META word right behind its food value — {p0, p1, food, META} in the interleaved record,
+// {food, META} records (fs = 2) otherwise — so the gather that fetches a perceived cell's food also
+// returns its wall / anthill / presence bits and its explored stamp:
+//   bits 0..15   PRESENCE STAMP: sequence number of the last observation in which an ant stood on the cell
+//                (RL_api.py:137-142): k_move stores the current number with one 2-byte store per ant, the ants
+//                channel is (stamp == current number).  No clearing pass, no read-modify-write, no atomics.
+//   bit 16       wall (Walls.map)          bit 17  anthill area (Anthill.area)
+//   bits 18..31  EXPLORED STAMP: sequence number of the first observation whose perception covered the cell,
+//                META_NEVER if none.  Observation number s counts a cell as unexplored iff stamp >= s (all
+//                ants count against the map as it was BEFORE this observation, reward_custom.py:19-22) and
+//                marks it by storing the upper half-word (s << 2 | wall / area bits) — a plain 2-byte store:
+//                every writer of one observation stores the same value.
+//   Sequence numbers run 1 .. META_NEVER - 2; the host then re-bases both stamps in one pass over the cells
+//   (explored cells -> stamp 0, presence -> 0) and restarts at 1: every 16 381 observations.
 #pragma once
 #include <stdint.h>
 #include "../../include/antsrl.h"
+
+#define META_PRES_MASK 0xFFFFu
+#define META_WALL 0x10000u
+#define META_AREA 0x20000u
+#define META_STAMP_SHIFT 18
+#define META_NEVER 0x3FFFu
+
+// PROF_ENV("NAME"): A/B and ablation switches exist in the profiling build only (-DANTSRL_PROFILING ->
+// libantsrl_hip_prof.so, see antsrl_amd/build.py); in the product library no environment variable can
+// change what a step computes.
+#ifdef ANTSRL_PROFILING
+#define PROF_ENV(name) getenv(name)
+#else
+#define PROF_ENV(name) ((const char *)nullptr)
+#endif
+
+struct __align__(16) AntFrame { double cx, cy, ct, st; }; // perception centre, cos/sin(theta + pi/2)
 
 struct DState {
     double *x, *y, *theta, *prev_x, *prev_y; // [E*N]
@@ -44,6 +77,8 @@ struct DState {
     int32_t *timestep;                       // [E]
     uint8_t *reward_primed;                  // [E]
     int32_t *gen_discs;                      // [E][ANTSRL_MAX_FOOD_DISCS][3] food discs of the device generator
+    // cell-meta layout only (KP::meta)
+    uint8_t *primed_cur;                     // [E]   reward_primed as the current observation must see it
 };
 
 // Kernel parameter block, passed by value (lives in the kernarg segment; every field is
@@ -64,6 +99,7 @@ struct KP {
     // holds u = v / f0^S_at_write; v_now = u * g_now with g = f0^S.  g == 1 in explicit mode.
     int32_t scaled, _pad;
     int32_t ps, fs;   // cell strides of the pheromone / food arrays, see DState
+    int32_t meta, _pad3; // 1: cell-meta layout (META word at food + 1), k_move + k_perceive instead of k_act
     double g_now;     // f0^S          : materialises values for the perception gather / read-out
     double g_dep;     // f0^(S+1)      : at deposit time, after the conceptual sweep of this update
     double inv_g_dep; // 1 / g_dep

@@ -1,0 +1,750 @@
+// antsrl_perceive.hip — RLApi.step (RL_api.py:168-204) / RLApi.observation (RL_api.py:96-165) on the
+// cell-meta layout (antsrl_device.h), as two kernels:
+//
+//   k_move      one workgroup per environment, one ant per thread: mandible decision + food exchange
+//               (RL_api.py:178-185, ants.py:102-117, LDS last-writer-wins), activation (ants.py:89-96),
+//               rotate, forward move (RL_api.py:190-196) and the presence stamp of the ant's cell
+//               (RL_api.py:137-142).  Every environment's workgroup is resident at once.
+//   k_perceive  the perception gather (RL_api.py:109-153) + rewards (rewards/reward_custom.py) + agent_state
+//               (RL_api.py:160-162).  ONE WAVE PER RUN OF ANTS, no per-environment state in LDS and no
+//               barrier after the prologue: each perceived cell is ONE gather that returns pheromone,
+//               food, wall / anthill / presence bits and the explored stamp (META word), so the work
+//               splits into (environment, segment) workgroups of any size — the chip never waits for an
+//               environment's per-ant phases and the tail is one short run per wave, not a 512-ant
+//               workgroup (round 1's k_act: 2 rounds of 512 resident workgroups, the first 20 us and
+//               the last 60 us of a 206 us launch half idle).
+//
+// No MFMA: nothing on this path is a dense contraction.  Host launchers at the end.
+#include "antsrl_util.h"
+#include "antsrl_flush.h"
+
+#define PRC_UNROLL 2 // ants in flight per wave (all their gathers are issued before the first is consumed)
+
+#define PLAYOUT_DEFAULT 1       // [Ants, Phero0, Phero1, Anthill, Walls, Food]   (generator order)
+#define PLAYOUT_DEFAULT_ROCKS 2 // ... + [CircleObstacles]
+
+// ---------------------------------------------------------------------------------------------------
+// k_move
+// ---------------------------------------------------------------------------------------------------
+__host__ __device__ inline size_t move_lds_bytes(int HT, int N)
+{
+    return align_up(8 * (size_t)HT + 12 * (size_t)N, 16);
+}
+
+template <int C>
+__global__ void __launch_bounds__(1024)
+k_move(const KP p, const int8_t *__restrict__ rotation, const int8_t *__restrict__ phero_act,
+       uint8_t *__restrict__ done, const int do_step, const uint32_t seq)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int e = blockIdx.x, tid = threadIdx.x, T = blockDim.x;
+    const int N = p.N, W = p.W, H = p.H, K = p.K;
+    const size_t G = (size_t)W * H, eN = (size_t)e * N;
+    uint32_t *hkeys = (uint32_t *)smem, *hvals = hkeys + p.HT;
+    float *tmp_q = (float *)(hvals + p.HT), *tmp_d = tmp_q + N;
+    uint32_t *cprevs = (uint32_t *)(tmp_d + N);
+
+    const uint32_t *area = p.s.area_bits + (size_t)e * p.words;
+    const FoodView food{p.s.food + (size_t)e * G * p.fs, p.fs};
+    // presence stamp of cell g (lower half-word of its META word): pres[g * 2 * fs]
+    uint16_t *pres = reinterpret_cast<uint16_t *>(p.s.food + (size_t)e * G * p.fs) + 2;
+    const size_t FS2 = 2 * (size_t)p.fs;
+
+    // One ant per thread (N <= T, the reference's sizes): every independent global load of the ant is issued
+    // here, ahead of the first barrier; the phases below use the registers.
+    const bool one = N <= T; // wave-uniform
+    const size_t a1 = eN + (tid < N ? tid : 0);
+    double h_x = 0.0, h_y = 0.0, h_th = 0.0;
+    float h_hold = 0.0f, h_q = 0.0f;
+    int h_m = 0, h_rot = 0, h_pa = 0;
+    uint32_t h_cprev = 0u;
+    if (one) {
+        h_x = p.s.x[a1]; h_y = p.s.y[a1]; h_th = p.s.theta[a1];
+        h_hold = p.s.holding[a1];
+        if (do_step) {
+            const double ppx = p.s.prev_x[a1], ppy = p.s.prev_y[a1];
+            h_m = p.s.mandibles[a1];
+            if (rotation) h_rot = rotation[a1];
+            if (phero_act) h_pa = phero_act[a1];
+            h_cprev = (uint32_t)((int)ppx * H + (int)ppy);
+            h_q = food[h_cprev]; // food is first written in phase 1b
+        }
+    }
+    if (do_step)
+        for (int h = tid; h < p.HT; h += T) {
+            hkeys[h] = HASH_EMPTY;
+            hvals[h] = 0u;
+        }
+    if (tid == 0) {
+        if (p.reward_kind != ANTSRL_REWARD_NONE) {
+            // the first observation after Reward.setup sees delta-holding == 0 (alias quirk,
+            // reward_custom.py:35,68): k_perceive reads the flag as it stood before this observation
+            p.s.primed_cur[e] = p.s.reward_primed[e];
+            p.s.reward_primed[e] = 1;
+        }
+        if (do_step && done) done[e] = (uint8_t)(p.max_time == p.s.timestep[e]); // RL_api.py:200
+    }
+    __syncthreads();
+
+    if (do_step) {
+        // ---- phase 1a: mandible target (RL_api.py:178-185) + Ants.update_mandibles reads
+        //      (ants.py:102-114).  All food reads happen before any food write.
+        for (int i = tid; i < N; i += T) {
+            double x, y;
+            uint32_t cprev;
+            float q, hold;
+            int old_m;
+            if (one) {
+                x = h_x; y = h_y; cprev = h_cprev; q = h_q; old_m = h_m; hold = h_hold;
+            } else {
+                x = p.s.x[eN + i]; y = p.s.y[eN + i];
+                cprev = (uint32_t)((int)p.s.prev_x[eN + i] * H + (int)p.s.prev_y[eN + i]);
+                q = food[cprev];
+                old_m = p.s.mandibles[eN + i];
+                hold = p.s.holding[eN + i];
+            }
+            const uint32_t ccur = (uint32_t)((int)x * H + (int)y);
+            int m = old_m;
+            for (int k = 0; k < K; ++k) { // perceived_objects order matters
+                if (p.ch_kind[k] == ANTSRL_CH_FOOD) m = (q > 0.0f) | m;                                // :182
+                else if (p.ch_kind[k] == ANTSRL_CH_ANTHILL) m = (1 - (int)test_bit(area, ccur)) & m;   // :184
+            }
+            const int closing = m & (1 - old_m), opening = (1 - m) & old_m; // ants.py:103-104
+            const float taken = fminf((float)p.max_hold, fmaxf(0.0f, q)) * (float)closing; // :111
+            const float dropped = hold * (float)opening;                                    // :114
+            h_hold = hold + (taken - dropped);                                              // :117
+            p.s.holding[eN + i] = h_hold;
+            p.s.mandibles[eN + i] = (uint8_t)m;                                             // :107
+            cprevs[i] = cprev;
+            tmp_q[i] = q;
+            tmp_d[i] = dropped - taken;
+            lww_insert(hkeys, hvals, (uint32_t)p.HT - 1, cprev, (uint32_t)i);
+        }
+        __syncthreads();
+        // ---- phase 1b: ants.py:116 `qte[cell] += dropped - taken`, last ant on a cell wins
+        for (int i = tid; i < N; i += T) {
+            const uint32_t cprev = cprevs[i];
+            const float delta = tmp_d[i];
+            int32_t dirty = -1;
+            if (delta != 0.0f && lww_winner(hkeys, hvals, (uint32_t)p.HT - 1, cprev) == (uint32_t)i) {
+                food[cprev] = tmp_q[i] + delta;
+                if (test_bit(area, cprev)) dirty = (int32_t)cprev;
+            }
+            p.s.dirty_cell[eN + i] = dirty;
+        }
+    }
+
+    // ---- phase 2: activation, rotate, move (RL_api.py:187-196), presence stamp
+    for (int i = tid; i < N; i += T) {
+        double x, y, th;
+        if (one) {
+            x = h_x; y = h_y; th = h_th;
+        } else {
+            x = p.s.x[eN + i]; y = p.s.y[eN + i]; th = p.s.theta[eN + i];
+        }
+        if (do_step) {
+            if (phero_act) { // Ants.activate_pheromone, ants.py:89-96
+                const int a = one ? h_pa : (int)phero_act[eN + i];
+                float a0 = 0.0f, a1 = 0.0f;
+                if (a == 1) a0 = (float)p.deposit_strength;
+                else if (a != 0) a1 = (float)p.deposit_strength;
+                p.s.activation[(eN + i) * C + 0] = a0;
+                if (C > 1) p.s.activation[(eN + i) * C + 1] = a1;
+            }
+            if (rotation) // Ants.rotate_ants + warp_theta, ants.py:62-67
+                th = np_mod_d(th + (double)(one ? h_rot : (int)rotation[eN + i]) * p.max_rot_speed, 2 * PI_D);
+            double sn, cs;
+            sincos(th, &sn, &cs);
+            // RL_api.py:194-196, Ants.forward_ants ants.py:77-80
+            double fwd = 1.0 * p.max_speed * (1 - (double)(one ? h_hold : p.s.holding[eN + i]) * p.carry);
+            if (fwd < 0) fwd *= p.backward;
+            x = warp_coord(x + cs * fwd, (double)W);
+            y = warp_coord(y + sn * fwd, (double)H);
+            p.s.x[eN + i] = x;
+            p.s.y[eN + i] = y;
+            p.s.theta[eN + i] = th;
+        }
+        // presence map, RL_api.py:137-141 (0/1, not a count): this observation's number into the cell's stamp
+        const uint32_t cell = (uint32_t)(wrap_index((int)x, W) * H + wrap_index((int)y, H));
+        pres[(size_t)cell * FS2] = (uint16_t)seq;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// k_perceive
+// ---------------------------------------------------------------------------------------------------
+// LDS: rock table of the workgroup's environment [R][4] doubles, then per wave: frames [run], rockmask
+// [run] (computed by the wave's own lanes in the prologue, one ant per lane), staging (two rows back to back +
+// alignment slack).
+struct PrcOff {
+    uint32_t rock, wave0, frame, rm, stage, per_wave, stride;
+    size_t total;
+};
+
+__host__ __device__ __forceinline__ PrcOff prc_offsets(int run, int PP, int K, int R, int nwaves)
+{
+    PrcOff o;
+    o.rock = 0;
+    o.wave0 = (uint32_t)(32 * (size_t)(R > 0 ? R : 1));
+    o.frame = 0;
+    o.rm = (uint32_t)(sizeof(AntFrame) * (size_t)run);
+    o.stage = (uint32_t)align_up(o.rm + 4 * (size_t)run, 16);
+    const size_t rowf = (size_t)PP * K;
+    o.stride = (uint32_t)((2 * rowf + 32 + 3) / 4 * 4); // floats: misalignment / carry (< one 128-byte line) + two rows
+    o.per_wave = (uint32_t)align_up(o.stage + 4 * (size_t)o.stride, 16);
+    o.total = o.wave0 + (size_t)nwaves * o.per_wave;
+    return o;
+}
+
+#define PRC_TPB 256
+
+// HAS_OBS is a template parameter on purpose: with the observation stores behind a run-time branch the
+// compiler cannot count them, every wait on a gather becomes vmcnt(0), i.e. a wait for the previous
+// group's observation stores to be acknowledged by memory — stores and everything else then add up instead
+// of overlapping (measured: 0.245 ms against 0.092 ms without the stores).
+template <int LAYOUT, bool OBS16, bool ILV, bool HAS_OBS>
+__global__ void __launch_bounds__(PRC_TPB, 4)
+k_perceive(const KP p, const float *__restrict__ cells, float *__restrict__ obs, float *__restrict__ agent_state,
+           float *__restrict__ reward, const int flags, const uint32_t seq, const int run, const int nseg)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    constexpr int C = 2;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int nwaves = PRC_TPB / 64;
+    const int N = p.N, W = p.W, H = p.H, K = p.K, P = p.P, PP = p.PP, R = p.R;
+    const size_t G = (size_t)W * H;
+    // (environment, segment) of this workgroup.  Workgroups are dealt round-robin over the 8 XCDs (b and
+    // b + 8 share one): all segments of an environment go to ONE XCD, back to back, so the cell records its
+    // ants share are fetched into one L2 (speed only — nothing depends on the placement).
+    int e, seg;
+    {
+        const int b = blockIdx.x;
+        if ((p.E & 7) == 0) {
+            const int j = b >> 3;
+            e = (j / nseg) * 8 + (b & 7);
+            seg = j % nseg;
+        } else {
+            e = b / nseg;
+            seg = b % nseg;
+        }
+    }
+    const PrcOff lo = prc_offsets(run, PP, K, R, nwaves);
+    double *rock = (double *)(smem + lo.rock);
+    unsigned char *wbase = smem + lo.wave0 + (size_t)wave * lo.per_wave;
+    AntFrame *frames = (AntFrame *)(wbase + lo.frame);
+    uint32_t *rmask = (uint32_t *)(wbase + lo.rm);
+    float *stage = (float *)(wbase + lo.stage);
+
+    const size_t eN = (size_t)e * N;
+    const int i_begin = min((seg * nwaves + wave) * run, N), i_end = min(i_begin + run, N);
+    const int n_run = i_end - i_begin; // wave-uniform, 0 for a wave past the end of the environment
+
+    // ---- prologue: rock table of the environment, this wave's frames and rock masks
+    for (int q = tid; q < R; q += PRC_TPB) {
+        const double rad = p.s.rock_r[(size_t)e * R + q];
+        rock[4 * q + 0] = p.s.rock_cx[(size_t)e * R + q];
+        rock[4 * q + 1] = p.s.rock_cy[(size_t)e * R + q];
+        rock[4 * q + 2] = rad;
+        rock[4 * q + 3] = sqrt_lt_threshold(rad);
+    }
+    __syncthreads(); // (the rock table is complete)
+    // The perception frame of every ant of this wave's run, one ant per lane (RL_api.py:100-108: centre shifted
+    // by `fwd_delta` along the heading, cos / sin of theta + pi/2), and the rocks whose disc can reach the patch
+    // (conservative; the exact test runs per cell below).
+    if (lane < n_run) {
+        const size_t a = eN + (size_t)i_begin + lane;
+        const double x = p.s.x[a], y = p.s.y[a], th = p.s.theta[a];
+        double xf = x, yf = y;
+        if (p.fwd_delta != 0.0) {
+            double sn, cs;
+            sincos(th, &sn, &cs);
+            xf += cs * p.fwd_delta;
+            yf += sn * p.fwd_delta;
+        }
+        double st, ct;
+        sincos(th + PI_D * 0.5, &st, &ct);
+        AntFrame fr;
+        fr.cx = xf; fr.cy = yf; fr.ct = ct; fr.st = st;
+        frames[lane] = fr;
+        uint32_t rm = 0u;
+        if (R > 0) {
+            const double margin = (double)p.r * p.delta * 1.4142135623730951 + 1.5;
+            const bool border = xf - margin < 0 || yf - margin < 0 || xf + margin >= W || yf + margin >= H;
+            for (int q = 0; q < R; ++q) {
+                const double dx = rock[4 * q + 0] - xf, dy = rock[4 * q + 1] - yf;
+                const double rr = rock[4 * q + 2] + margin;
+                if (border || dx * dx + dy * dy < rr * rr) rm |= 1u << q;
+            }
+        }
+        rmask[lane] = rm;
+    }
+    wave_lds_sync();
+    if (n_run <= 0) return; // (no barrier below: waves run independently from here on)
+
+    const float *ph = cells + (size_t)e * G * (size_t)p.ps;
+    const float *fm = p.s.food + (size_t)e * G * p.fs; // {food, META} records when not interleaved
+    uint32_t *metaw = reinterpret_cast<uint32_t *>(p.s.food + (size_t)e * G * p.fs) + 1;
+    const size_t FS = (size_t)p.fs;
+    const bool explore = p.explore_on != 0;
+    constexpr bool has_obs = HAS_OBS;
+    // ablations: compile-time only (variant builds for profiles/, results are wrong by design)
+#ifdef PRC_ABL_NO_GATHER
+    constexpr bool abl_gather = true;
+#else
+    constexpr bool abl_gather = false;
+#endif
+#ifdef PRC_ABL_NO_STORE
+    constexpr bool abl_store = true;
+#else
+    constexpr bool abl_store = false;
+#endif
+#ifdef PRC_ABL_NO_MARK
+    constexpr bool abl_mark = true;
+#else
+    constexpr bool abl_mark = false;
+#endif
+#ifdef PRC_ABL_STORE_REGS // the copy-out stores take register values: no LDS read in front of them
+    constexpr bool abl_regs = true;
+#else
+    constexpr bool abl_regs = false;
+#endif
+#ifdef PRC_ABL_NO_STAGE // no LDS staging writes
+    constexpr bool abl_stage = true;
+#else
+    constexpr bool abl_stage = false;
+#endif
+    const float inv_max = 1.0f / (float)p.max_val;
+    const float g_now = (float)p.g_now;                       // scaled mode: v = u * f0^S ...
+    const float cut = p.scaled ? (float)p.threshold : 0.0f;   // ... and 0 below the 0.01 cut
+    const uint32_t row = (uint32_t)PP * (uint32_t)K;            // elements per ant
+    const bool wrap_fast = W > 4 * (p.r + 4) && H > 4 * (p.r + 4) && p.fwd_delta < W / 4 && p.fwd_delta < H / 4 &&
+                           p.fwd_delta > -W / 4 && p.fwd_delta > -H / 4 && p.delta < 2.0;
+    const bool wrap_pow2 = (W & (W - 1)) == 0 && (H & (H - 1)) == 0;
+
+    // ---- perception: one LANE per perceived cell (49 of 64 lanes at the reference's 7x7): the cell's
+    // offsets, mask bit and output slot are per-lane constants, the ant's frame is wave-uniform (LDS
+    // broadcast).  Software-pipelined by one group of PRC_UNROLL ants; everything that touches global memory
+    // is straight-line and unconditional (out-of-range ants / lanes are clamped onto valid ones and redo
+    // identical work: stores of the same value to the same address), so the compiler can count outstanding
+    // operations: the wait for group g's gathers leaves group g+1's gathers and group g-1's stores in flight.
+    const int q = lane < PP ? lane : PP - 1; // lanes beyond the perception clamp onto its last cell
+    const double of_px = (double)(q % P - p.r) * p.delta; // coords[a][b] = (arange[b], arange[a]) * DELTA, RL_api.py:92-93
+    const double of_py = (double)(q / P - p.r) * p.delta;
+    const bool mask_q = p.has_mask ? p.mask[q] != 0 : true;
+    const uint32_t qK = (uint32_t)q * K;
+    // A lane whose gathered record is never used (a masked cell when no reward counts explored cells) takes
+    // the address of the wave's first needed lane: the CU's address path works through a scattered gather at
+    // about one distinct address per clock, and a lane on an address that is fetched anyway costs nothing.
+#ifdef PRC_ABL_MERGE_MASKED // ablation: masked lanes never gather their own cell (explored counts are then wrong)
+    const bool own = mask_q;
+#else
+    const bool own = mask_q || explore;
+#endif
+    const unsigned long long need_mask = __ballot(own);
+    const int src_lane = own ? lane : (need_mask ? __builtin_ctzll(need_mask) : 0);
+
+#if defined(PRC_GATHER_NT)
+#define PRC_LOAD4(ptr) __builtin_nontemporal_load(reinterpret_cast<const stream_f4 *>(ptr))
+#else
+#define PRC_LOAD4(ptr) (*reinterpret_cast<const stream_f4 *>(ptr))
+#endif
+#define PRC_FETCH(G0, CELL, IXV, IYV, PVV, FDV, MTV)                                                     \
+    {                                                                                                    \
+        _Pragma("unroll") for (int u = 0; u < PRC_UNROLL; ++u)                                           \
+        {                                                                                                \
+            const int j_ = min((G0) + u, n_run - 1);                                                     \
+            const AntFrame fr = frames[j_]; /* wave-uniform address: LDS broadcast */                    \
+            const double rx = fr.ct * of_px - fr.st * of_py; /* RL_api.py:110-111 */                     \
+            const double ry = fr.st * of_px + fr.ct * of_py;                                             \
+            int ix = (int)rint(rx + fr.cx), iy = (int)rint(ry + fr.cy); /* :114-117 half to even */      \
+            if (wrap_pow2) { /* :118-119; two's complement AND is the floor-mod for a power of two */    \
+                ix &= W - 1; iy &= H - 1;                                                                \
+            } else if (wrap_fast) { /* |ix| < 2W: unsigned min picks the in-range candidate */           \
+                ix = (int)min(min((uint32_t)ix, (uint32_t)(ix + W)), (uint32_t)(ix - W));                \
+                iy = (int)min(min((uint32_t)iy, (uint32_t)(iy + H)), (uint32_t)(iy - H));                \
+            } else {                                                                                     \
+                ix = wrap_index(ix, W); iy = wrap_index(iy, H);                                          \
+            }                                                                                            \
+            IXV[u] = ix; IYV[u] = iy;                                                                    \
+            CELL[u] = (uint32_t)(ix * H + iy);                                                           \
+        }                                                                                                \
+        _Pragma("unroll") for (int u = 0; u < PRC_UNROLL; ++u)                                           \
+        {                                                                                                \
+            const uint32_t gc_ = abl_gather ? (uint32_t)lane : (uint32_t)__shfl((int)CELL[u], src_lane); \
+            if (ILV) { /* one {p0, p1, food, META} record per cell: a single 16-byte gather */           \
+                const stream_f4 t = PRC_LOAD4(ph + (size_t)gc_ * 4);                                     \
+                PVV[u][0] = t.x; PVV[u][1] = t.y; FDV[u] = t.z; MTV[u] = __float_as_uint(t.w);           \
+            } else {                                                                                     \
+                const float2 t = *reinterpret_cast<const float2 *>(ph + (size_t)gc_ * 2);                \
+                const float2 f = *reinterpret_cast<const float2 *>(fm + (size_t)gc_ * 2);                \
+                PVV[u][0] = t.x; PVV[u][1] = t.y; FDV[u] = f.x; MTV[u] = __float_as_uint(f.y);           \
+            }                                                                                            \
+        }                                                                                                \
+    }
+    uint32_t c_cell[PRC_UNROLL], n_cell[PRC_UNROLL], c_mt[PRC_UNROLL], n_mt[PRC_UNROLL];
+    int c_ix[PRC_UNROLL], c_iy[PRC_UNROLL], n_ix[PRC_UNROLL], n_iy[PRC_UNROLL];
+    float c_pv[PRC_UNROLL][C], n_pv[PRC_UNROLL][C], c_fd[PRC_UNROLL], n_fd[PRC_UNROLL];
+    uint32_t cntv = 0u; // lane j: unexplored cells in the patch of ant i_begin + j
+    // copy-out state: elements per 128-byte line / per 16 bytes, the run's first row, the aligned line the LDS
+    // image currently starts at, and how many image elements in front of the next row are already taken
+    constexpr uint32_t LINE = OBS16 ? 64u : 32u, VEC = OBS16 ? 8u : 4u, ESZ = OBS16 ? 2u : 4u;
+    unsigned char *run0 = reinterpret_cast<unsigned char *>(obs) + ((size_t)e * N + (size_t)i_begin) * row * ESZ;
+#ifndef PRC_FLUSH_LINES
+    uint32_t carry = has_obs ? (uint32_t)(((uintptr_t)run0 & 15) / ESZ) : 0u;
+#else
+    uint32_t carry = has_obs ? (uint32_t)(((uintptr_t)run0 & 127) / ESZ) : 0u;
+#endif
+    unsigned char *line_base = run0 - (size_t)carry * ESZ;
+    (void)LINE; (void)VEC; (void)line_base; (void)abl_store; (void)abl_regs;
+    PRC_FETCH(0, c_cell, c_ix, c_iy, c_pv, c_fd, c_mt)
+    // The loop is entered with NO load pending: the compiler's wait-count analysis merges the loop-entry state
+    // with the back-edge state, and a prologue gather still in flight at the loop head turns into a
+    // `vmcnt(2)` in the steady state, i.e. a wait for the previous group's observation stores half an
+    // iteration after they were issued.  (vmcnt(0), expcnt / lgkmcnt untouched.)
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    for (int j0 = 0; j0 < n_run; j0 += PRC_UNROLL) {
+        PRC_FETCH(min(j0 + PRC_UNROLL, n_run - 1), n_cell, n_ix, n_iy, n_pv, n_fd, n_mt) // (clamped: harmless re-read at the end)
+#pragma unroll
+        for (int u = 0; u < PRC_UNROLL; ++u) {
+            const int j = min(j0 + u, n_run - 1);
+            const bool real = (j0 + u < n_run) && lane < PP; // clamped duplicates must not count twice
+            const uint32_t mt = c_mt[u];
+            // reward_custom.py:19,22 (mask ignored): unexplored before THIS observation <=> stamp >= seq
+            const bool unexp = real && explore && (mt >> META_STAMP_SHIFT) >= seq;
+            const uint32_t n_un = (uint32_t)__popcll(__ballot(unexp));
+            cntv = (lane == j0 + u) ? n_un : cntv; // (a clamped duplicate lands on a lane past the run: never read)
+            // mark: the stamp half-word of the META word := seq.  A plain 2-byte store, no atomic: every writer of
+            // this observation stores the same value, cells explored earlier (stamp < seq) are never written, and
+            // a reader that still sees the old stamp counts the cell as unexplored just the same (stamp >= seq).
+            if (unexp && !abl_mark)
+                reinterpret_cast<uint16_t *>(metaw)[(size_t)c_cell[u] * FS * 2 + 1] = (uint16_t)((seq << 2) | ((mt >> 16) & 3u));
+            if (has_obs) {
+                float pvs[C];
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    float v = c_pv[u][c];
+                    if (p.scaled) {
+                        v *= g_now;
+                        v = v < cut ? 0.0f : v;
+                    }
+                    pvs[c] = v * inv_max; // :124-125, reciprocal multiply (pheromone channels are held to 1e-5)
+                }
+                const float v_ants = (mt & META_PRES_MASK) == seq ? 1.0f : 0.0f; // :142
+                const float v_area = (mt & META_AREA) ? 1.0f : 0.0f;  // :130-131
+                const float v_wall = (mt & META_WALL) ? 1.0f : 0.0f;  // :128-129
+                float v_rock = 0.0f;                                  // :132-135
+                if (LAYOUT == PLAYOUT_DEFAULT_ROCKS) {
+                    uint32_t rm = mask_q ? rmask[j] : 0u;
+                    bool any = false;
+                    while (rm) {
+                        const int r = __builtin_ctz(rm);
+                        rm &= rm - 1;
+                        const double vx = (double)c_ix[u] - rock[4 * r + 0];
+                        const double vy = (double)c_iy[u] - rock[4 * r + 1];
+                        any |= vx * vx + vy * vy < rock[4 * r + 3]; // == sqrt(d2) < radius, see sqrt_lt_threshold
+                    }
+                    v_rock = any ? 1.0f : 0.0f;
+                }
+                const bool m = mask_q; // RL_api.py:147-148: mask*(p+1)-1 == -1 on masked cells
+                if (abl_stage) {
+                    asm volatile("" ::"v"(v_ants), "v"(pvs[0]), "v"(pvs[1]), "v"(v_area), "v"(v_wall), "v"(c_fd[u]), "v"(v_rock));
+                } else if (OBS16) {
+                    // bfloat16 observations: the same staging and copy-out on 2-byte elements (8 per 16 bytes)
+                    uint16_t *o16 = reinterpret_cast<uint16_t *>(stage) + carry + (uint32_t)u * row + qK;
+                    o16[0] = bf16_bits(m ? v_ants : -1.0f); o16[1] = bf16_bits(m ? pvs[0] : -1.0f);
+                    o16[2] = bf16_bits(m ? pvs[1] : -1.0f); o16[3] = bf16_bits(m ? v_area : -1.0f);
+                    o16[4] = bf16_bits(m ? v_wall : -1.0f); o16[5] = bf16_bits(m ? c_fd[u] : -1.0f);
+                    if (LAYOUT == PLAYOUT_DEFAULT_ROCKS) o16[6] = bf16_bits(m ? v_rock : -1.0f);
+                } else {
+                    // float32: the group's rows are staged back to back behind the carry, as they lie in memory
+                    // (the image mirrors the destination modulo one 128-byte line), and flushed together below
+                    float *o = stage + carry + (uint32_t)u * row + qK;
+                    o[0] = m ? v_ants : -1.0f; o[1] = m ? pvs[0] : -1.0f; o[2] = m ? pvs[1] : -1.0f;
+                    o[3] = m ? v_area : -1.0f; o[4] = m ? v_wall : -1.0f; o[5] = m ? c_fd[u] : -1.0f;
+                    if (LAYOUT == PLAYOUT_DEFAULT_ROCKS) o[6] = m ? v_rock : -1.0f;
+                }
+            }
+        }
+#ifndef PRC_FLUSH_LINES // the three-store copy-out (antsrl_flush.h: flush_plan_f32 / flush_plan_b16)
+        if (has_obs) {
+            // The group's rows are contiguous in memory and leave as ONE run: 16-byte stores over the interior
+            // pieces (the first 128 / 64 of them start on a 128-byte line), one element-wide store for the edge
+            // elements; lanes with nothing left repeat a valid store.  Measured against the whole-line copy-out
+            // with carry (-DPRC_FLUSH_LINES) on one box: 0.252 vs 0.267 ms.
+            wave_lds_sync();
+            const uint32_t rowp = (j0 + 1 < n_run) ? 2u * row : row; // (odd tail of the run: one row)
+            if (OBS16) {
+                uint16_t *dst16 = reinterpret_cast<uint16_t *>(obs) + ((size_t)e * N + (size_t)(i_begin + j0)) * row;
+                const uint32_t mis16 = (uint32_t)(((uintptr_t)dst16 >> 1) & 7);
+                uint16_t *st16 = reinterpret_cast<uint16_t *>(stage), *d_al = dst16 - mis16;
+                const FlushPlanB16 f = flush_plan_b16((uint32_t)lane, mis16, rowp, (uint32_t)((uintptr_t)d_al >> 4) & 7u);
+                const uint4 w1 = reinterpret_cast<const uint4 *>(st16)[f.g1];
+                const uint4 w2 = reinterpret_cast<const uint4 *>(st16)[f.g2];
+                const uint16_t we = st16[f.fe];
+                if (!abl_store) {
+                    store_stream(reinterpret_cast<uint4 *>(d_al) + f.g1, w1);
+                    store_stream(reinterpret_cast<uint4 *>(d_al) + f.g2, w2);
+                    store_stream(d_al + f.fe, we);
+                }
+                carry = (uint32_t)(((uintptr_t)(dst16 + rowp) >> 1) & 7); // the next group's 16-byte misalignment
+            } else {
+                float *dst = reinterpret_cast<float *>(obs) + ((size_t)e * N + (size_t)(i_begin + j0)) * row;
+                const uint32_t mis = (uint32_t)(((uintptr_t)dst >> 2) & 3);
+                float *dst_al = dst - mis;
+                const FlushPlanF32 f = flush_plan_f32((uint32_t)lane, mis, rowp, (uint32_t)((uintptr_t)dst_al >> 4) & 7u);
+                float4 v1, v2, v3;
+                float ve;
+                if (abl_regs) {
+                    v1 = make_float4(c_pv[0][0], c_pv[0][1], c_fd[0], 1.0f); v2 = make_float4(c_pv[1][0], c_pv[1][1], c_fd[1], 2.0f);
+                    v3 = v1; ve = c_fd[0];
+                } else {
+                    v1 = reinterpret_cast<const float4 *>(stage)[f.j1];
+                    v2 = reinterpret_cast<const float4 *>(stage)[f.j2];
+                    v3 = reinterpret_cast<const float4 *>(stage)[f.j3];
+                    ve = stage[f.fe];
+                }
+                if (!abl_store) {
+                    store_stream(reinterpret_cast<float4 *>(dst_al) + f.j1, v1);
+                    store_stream(reinterpret_cast<float4 *>(dst_al) + f.j2, v2);
+                    store_stream(reinterpret_cast<float4 *>(dst_al) + f.j3, v3);
+                    store_stream(dst_al + f.fe, ve);
+                }
+                carry = (uint32_t)(((uintptr_t)(dst + rowp) >> 2) & 3); // the next group's 16-byte misalignment
+            }
+            wave_lds_sync();
+        }
+#else
+        if (has_obs) {
+            // whole-line copy-out with carry (antsrl_flush.h): every store instruction covers whole aligned
+            // 128-byte lines of this wave's own rows
+            wave_lds_sync();
+            const uint32_t rowp = (j0 + 1 < n_run) ? 2u * row : row; // (odd tail of the run: one row)
+            const LineFlush f = line_flush(carry, rowp, j0 == 0, LINE, VEC);
+            if (OBS16) {
+                const uint16_t *st16 = reinterpret_cast<const uint16_t *>(stage);
+                uint16_t *lb = reinterpret_cast<uint16_t *>(line_base);
+                const uint32_t g1 = line_piece((uint32_t)lane, 0, f), g2 = line_piece((uint32_t)lane, 1, f);
+                const uint4 w1 = reinterpret_cast<const uint4 *>(st16)[g1];
+                const uint4 w2 = reinterpret_cast<const uint4 *>(st16)[g2];
+                const uint16_t wl = st16[f.nl * LINE + min((uint32_t)lane, max(f.left, 1u) - 1u)]; // the next carry
+                if (!abl_store) {
+                    store_stream(reinterpret_cast<uint4 *>(lb) + g1, w1);
+                    store_stream(reinterpret_cast<uint4 *>(lb) + g2, w2);
+                    if (f.head) { // first flush of the run only: the elements in front of the first whole piece
+                        const uint32_t h = carry + min((uint32_t)lane, f.head - 1u);
+                        store_stream(lb + h, st16[h]);
+                    }
+                }
+                wave_lds_sync();
+                if ((uint32_t)lane < f.left) reinterpret_cast<uint16_t *>(stage)[lane] = wl;
+            } else {
+                float *lb = reinterpret_cast<float *>(line_base);
+                const uint32_t j1 = line_piece((uint32_t)lane, 0, f), j2 = line_piece((uint32_t)lane, 1, f),
+                               j3 = line_piece((uint32_t)lane, 2, f);
+                float4 v1, v2, v3;
+                if (abl_regs) {
+                    v1 = make_float4(c_pv[0][0], c_pv[0][1], c_fd[0], 1.0f); v2 = make_float4(c_pv[1][0], c_pv[1][1], c_fd[1], 2.0f);
+                    v3 = v1;
+                } else {
+                    v1 = reinterpret_cast<const float4 *>(stage)[j1];
+                    v2 = reinterpret_cast<const float4 *>(stage)[j2];
+                    v3 = reinterpret_cast<const float4 *>(stage)[j3];
+                }
+                const float vl = stage[f.nl * LINE + min((uint32_t)lane, max(f.left, 1u) - 1u)]; // the next carry
+                if (!abl_store) {
+                    store_stream(reinterpret_cast<float4 *>(lb) + j1, v1);
+                    store_stream(reinterpret_cast<float4 *>(lb) + j2, v2);
+                    store_stream(reinterpret_cast<float4 *>(lb) + j3, v3);
+                    if (f.head) { // first flush of the run only: the <= 3 floats in front of the first whole piece
+                        const uint32_t h = carry + min((uint32_t)lane, f.head - 1u);
+                        store_stream(lb + h, stage[h]);
+                    }
+                }
+                wave_lds_sync();
+                if ((uint32_t)lane < f.left) stage[lane] = vl;
+            }
+            line_base += (size_t)f.nl * 128;
+            carry = f.left;
+            wave_lds_sync();
+        }
+#endif
+#pragma unroll
+        for (int u = 0; u < PRC_UNROLL; ++u) {
+            c_cell[u] = n_cell[u]; c_ix[u] = n_ix[u]; c_iy[u] = n_iy[u]; c_fd[u] = n_fd[u]; c_mt[u] = n_mt[u];
+#pragma unroll
+            for (int c = 0; c < C; ++c) c_pv[u][c] = n_pv[u][c];
+        }
+    }
+#undef PRC_FETCH
+#ifdef PRC_FLUSH_LINES
+    if (has_obs && carry && !abl_store) { // the run's last, partial line: element-wide stores (the next run owns the rest)
+        if (OBS16) {
+            if ((uint32_t)lane < carry)
+                store_stream(reinterpret_cast<uint16_t *>(line_base) + lane, reinterpret_cast<const uint16_t *>(stage)[lane]);
+        } else {
+            if ((uint32_t)lane < carry) store_stream(reinterpret_cast<float *>(line_base) + lane, stage[lane]);
+        }
+    }
+#endif
+
+    // ---- agent_state (RL_api.py:160-162), reward.observation hooks, give_reward: lane j <-> ant i_begin + j
+    if (lane < n_run) {
+        const size_t a = eN + (size_t)i_begin + lane;
+        const float hold = p.s.holding[a];
+        if (agent_state) {
+            store_stream(agent_state + a * 2 + 0, hold);
+            store_stream(agent_state + a * 2 + 1, p.s.seed[a]);
+        }
+        double rw = 0.0;
+        if (p.reward_kind != ANTSRL_REWARD_NONE) {
+            const float prev_h = p.s.primed_cur[e] ? p.s.prev_holding[a] : hold;
+            const double dh = (double)hold - (double)prev_h;
+            if (p.reward_kind == ANTSRL_REWARD_EXPLORATION) {
+                rw = (double)cntv / 10.0; // reward_custom.py:19
+            } else if (p.reward_kind == ANTSRL_REWARD_FOOD) {
+                rw = dh < 0 ? 10.0 : dh; // reward_custom.py:38-39
+                p.s.prev_holding[a] = hold;
+            } else { // All_Rewards, reward_custom.py:79-106
+                const double r_food = dh < 0 ? 0.0 : dh;
+                const double r_anthill = dh < 0 ? 1.0 : 0.0;
+                p.s.prev_holding[a] = hold;
+                if (explore) {
+                    double re = (double)cntv / 10.0;
+                    re = (hold == 0.0f) ? re * p.fct_explore : re * p.fct_explore_holding;
+                    rw += re;
+                }
+                const double dx = p.s.x[a] - (double)p.s.anthill_xyr[3 * e + 0];
+                const double dy = p.s.y[a] - (double)p.s.anthill_xyr[3 * e + 1];
+                const double nd = sqrt(dx * dx + dy * dy);
+                const double heading = (double)((p.s.prev_dist[a] > nd) && (hold > 0.0f)) * 0.1;
+                p.s.prev_dist[a] = nd;
+                rw += r_food * p.fct_food + r_anthill * p.fct_anthill + heading * p.fct_heading;
+            }
+        }
+        if (reward) store_stream(reward + a, (float)rw);
+        if ((flags & ACT_STEP) && rw - p.reward_threshold > 0) p.s.reward_state[a] = 255; // ants.py:119-121
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// cell-meta maintenance (not on the hot path)
+// ---------------------------------------------------------------------------------------------------
+// Re-base the stamps before the observation counter can reach META_NEVER: every explored cell gets explored
+// stamp 0, every presence stamp 0, the counter restarts at 1 (16 381 observations apart).
+__global__ void k_meta_rebase(const KP p)
+{
+    const size_t n = (size_t)p.E * p.W * p.H;
+    uint32_t *m = reinterpret_cast<uint32_t *>(p.s.food) + 1;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const uint32_t v = m[i * p.fs];
+        m[i * p.fs] = (v & (META_WALL | META_AREA)) | ((v >> META_STAMP_SHIFT) != META_NEVER ? 0u : META_NEVER << META_STAMP_SHIFT);
+    }
+}
+
+// ===================================================================================
+// host-side launchers (called from antsrl_capi.hip)
+// ===================================================================================
+static int prc_layout(const KP &p)
+{
+    static const int def[7] = {ANTSRL_CH_ANTS, ANTSRL_CH_PHERO, ANTSRL_CH_PHERO, ANTSRL_CH_ANTHILL,
+                               ANTSRL_CH_WALLS, ANTSRL_CH_FOOD, ANTSRL_CH_ROCKS};
+    if (p.C != 2 || (p.K != 6 && p.K != 7)) return 0;
+    for (int k = 0; k < p.K; ++k)
+        if (p.ch_kind[k] != def[k]) return 0;
+    if (p.ch_arg[1] != 0 || p.ch_arg[2] != 1) return 0;
+    return p.K == 6 ? PLAYOUT_DEFAULT : PLAYOUT_DEFAULT_ROCKS;
+}
+
+// Which configurations take the cell-meta path: the reference's perception shapes (the generator's channel
+// order with 2 pheromone channels, a perception of at most 64 cells whose two-row group leaves in three
+// 16-byte stores per lane) with at most 4096 ants per env (k_move's hash and exchange scratch are LDS-resident).
+bool antsrl_meta_supported(const KP &p)
+{
+    const uint32_t row = (uint32_t)p.PP * p.K;
+    // (row >= 128 elements: every copy-out then has at least two whole 128-byte lines in either observation format)
+    return prc_layout(p) != 0 && p.PP <= 64 && row >= 128 && row <= 368 && p.N <= 4096 &&
+           move_lds_bytes(p.HT, p.N) <= 160 * 1024;
+}
+
+static int n_cus()
+{
+    static int n[ANTSRL_MAX_DEVICES] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= ANTSRL_MAX_DEVICES) return 256;
+    if (!n[dev] && hipDeviceGetAttribute(&n[dev], hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n[dev] = 256;
+    return n[dev] > 0 ? n[dev] : 256;
+}
+
+// Ants per wave of k_perceive: long runs amortise the prologue and keep a wave's rows one sequential write
+// stream; short runs fill the chip (16 waves per CU) several times over so that the tail is short.
+static int pick_run(const KP &p)
+{
+    if (const char *s = PROF_ENV("ANTSRL_PRC_RUN")) return atoi(s);
+    const long total = (long)p.E * p.N, slots = (long)n_cus() * 16;
+    // c3 (1024 x 512 ants), k_perceive ms early / late in the episode: run 2: 0.313 / 0.308, 4: 0.253 / 0.247,
+    // 8: 0.236 / 0.231, 16: 0.237 (late), 32: 0.250 / 0.245, 64: 0.250 (late) — with short runs the segments of one
+    // environment run close together in time and share its cell records in L2 (profiles/r02/prc_run_sweep.txt)
+    int run = 8;
+    while (run > 2 && total / run < slots) run >>= 1; // tiny batches: at least one wave per slot
+    return run;
+}
+
+int antsrl_perceive_run(const KP &p) { return pick_run(p); }
+
+hipError_t antsrl_launch_move(const KP &p, const int8_t *rot, const int8_t *ph, uint8_t *done, int do_step,
+                              uint32_t seq, hipStream_t st)
+{
+    const int T = p.N <= 1024 ? (p.N + 63) / 64 * 64 : 1024;
+    const size_t lds = move_lds_bytes(p.HT, p.N);
+    static size_t seen[ANTSRL_MAX_DEVICES] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= ANTSRL_MAX_DEVICES) return hipErrorInvalidDevice;
+    if (lds > 64 * 1024 && lds > seen[dev]) {
+        hipError_t err = hipFuncSetAttribute((const void *)k_move<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (err != hipSuccess) return err;
+        seen[dev] = lds;
+    }
+    hipLaunchKernelGGL((k_move<2>), dim3(p.E), dim3(T), lds, st, p, rot, ph, done, do_step, seq);
+    return hipGetLastError();
+}
+
+template <int LAYOUT, bool OBS16, bool ILV, bool HAS_OBS>
+static hipError_t launch_perceive_t(const KP &p, const float *cells, float *obs, float *agent_state, float *reward,
+                                    int flags, uint32_t seq, hipStream_t st)
+{
+    const int run = pick_run(p), nwaves = PRC_TPB / 64;
+    if (run < 1 || run > 64) return hipErrorInvalidValue;
+    const int nseg = (p.N + run * nwaves - 1) / (run * nwaves);
+    const PrcOff lo = prc_offsets(run, p.PP, p.K, p.R, nwaves);
+    const size_t pad = PROF_ENV("ANTSRL_PRC_LDS_PAD") ? (size_t)atoi(PROF_ENV("ANTSRL_PRC_LDS_PAD")) * 1024 : 0; // occupancy knob
+    hipLaunchKernelGGL((k_perceive<LAYOUT, OBS16, ILV, HAS_OBS>), dim3((unsigned)((size_t)p.E * nseg)), dim3(PRC_TPB), lo.total + pad, st, p,
+                       cells, obs, agent_state, reward, flags, seq, run, nseg);
+    return hipGetLastError();
+}
+
+hipError_t antsrl_launch_perceive(const KP &p, int cur, float *obs, float *agent_state, float *reward, int flags,
+                                  uint32_t seq, hipStream_t st)
+{
+    const int layout = prc_layout(p);
+    const bool o16 = (flags & ACT_OBS_BF16) != 0, ilv = p.ps == 4 && p.fs == 4;
+    const float *cells = p.s.phero[cur];
+#define PRC_GO(LY)                                                                                             \
+    {                                                                                                          \
+        if (!obs) return launch_perceive_t<LY, false, ILVV, false>(p, cells, obs, agent_state, reward, flags, seq, st); \
+        if (o16) return launch_perceive_t<LY, true, ILVV, true>(p, cells, obs, agent_state, reward, flags, seq, st);    \
+        return launch_perceive_t<LY, false, ILVV, true>(p, cells, obs, agent_state, reward, flags, seq, st);            \
+    }
+#define PRC_GO2(LY) { if (ilv) { constexpr bool ILVV = true; PRC_GO(LY) } else { constexpr bool ILVV = false; PRC_GO(LY) } }
+    if (layout == PLAYOUT_DEFAULT) PRC_GO2(PLAYOUT_DEFAULT)
+    if (layout == PLAYOUT_DEFAULT_ROCKS) PRC_GO2(PLAYOUT_DEFAULT_ROCKS)
+#undef PRC_GO2
+#undef PRC_GO
+    return hipErrorInvalidValue;
+}
+
+hipError_t antsrl_launch_meta_rebase(const KP &p, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_meta_rebase, dim3(grid_for((size_t)p.E * p.W * p.H)), dim3(256), 0, st, p);
+    return hipGetLastError();
+}

@@ -14,7 +14,7 @@
 // the observation rows stream from HBM exactly once, as 32-byte pieces per lane.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-#include "../../include/antsrl.h"
+#include "antsrl_device.h"
 #define ANTSRL_MAX_DEVICES 64 // per-device launch bookkeeping (dynamic-LDS opt-in), as in antsrl_util.h
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -435,7 +435,7 @@ hipError_t antsrl_launch_policy(const float *obs, const float *agent_state, cons
     {
         // flat-stream form: W1 (observation columns) + two wave-private tile images (32 F elements + the
         // read-ahead of the last k-step, zero padded) in LDS
-        static const bool off = getenv("ANTSRL_POLICY_CHUNKED") != nullptr; // A/B: the chunked kernel
+        static const bool off = PROF_ENV("ANTSRL_POLICY_CHUNKED") != nullptr; // A/B: the chunked kernel
         const int ks = (F + 15) / 16, tile_elems = (32 * F + 32 + 7) / 8 * 8;
         const size_t lds = (size_t)POL_HIDDEN * (16 * ks + 8) * 2 + 2 * (size_t)tile_elems * 2;
         if (!off && ks <= POL_MAX_KSTEPS && lds <= 160 * 1024) {
@@ -471,11 +471,27 @@ hipError_t antsrl_launch_policy(const float *obs, const float *agent_state, cons
     int per_cu = (int)((160 * 1024) / lds); // resident workgroups per CU by LDS (38-41 KiB each for the reference's sizes)
     per_cu = per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu);
     if (blocks > 256 * per_cu) blocks = 256 * per_cu; // tiles are looped: one round of workgroups
-    if (obs_bf16)
+    // more than 64 KiB of dynamic LDS is an opt-in per kernel function and per device (like k_policy_flat, k_act)
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= ANTSRL_MAX_DEVICES) return hipErrorInvalidDevice;
+    if (obs_bf16) {
+        static size_t attr[ANTSRL_MAX_DEVICES] = {};
+        if (lds > attr[dev]) {
+            hipError_t e = hipFuncSetAttribute((const void *)k_policy_mlp<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+            attr[dev] = lds;
+        }
         hipLaunchKernelGGL(k_policy_mlp<true>, dim3(blocks), dim3(256), lds, st, obs, agent_state, w1, b1, w2, b2, w3, b3,
                            rot, ph, logits, M, F, ksteps);
-    else
+    } else {
+        static size_t attr[ANTSRL_MAX_DEVICES] = {};
+        if (lds > attr[dev]) {
+            hipError_t e = hipFuncSetAttribute((const void *)k_policy_mlp<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+            attr[dev] = lds;
+        }
         hipLaunchKernelGGL(k_policy_mlp<false>, dim3(blocks), dim3(256), lds, st, obs, agent_state, w1, b1, w2, b2, w3, b3,
                            rot, ph, logits, M, F, ksteps);
+    }
     return hipGetLastError();
 }

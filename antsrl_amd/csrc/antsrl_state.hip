@@ -70,6 +70,10 @@ __global__ void k_reset_grids(const KP p, const float *__restrict__ food, const 
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const size_t e = i / G, g = i - e * G;
         p.s.food[i * p.fs] = food[i];
+        if (p.meta) // wall / anthill bits (k_reset_bits ran before on this stream), no ant, never explored
+            reinterpret_cast<uint32_t *>(p.s.food)[i * p.fs + 1] =
+                (test_bit(p.s.walls_bits + e * p.words, (uint32_t)g) ? META_WALL : 0u) |
+                (test_bit(p.s.area_bits + e * p.words, (uint32_t)g) ? META_AREA : 0u) | (META_NEVER << META_STAMP_SHIFT);
         for (int c = 0; c < p.C; ++c) {
             const float v = phero ? phero[(e * p.C + c) * G + g] : 0.0f;
             p.s.phero[0][i * p.ps + c] = v;
@@ -205,6 +209,9 @@ __global__ void k_gen_cells(const KP p, const AntsGen g, const uint64_t seed)
             if (area) ab |= 1u << b;
             if (wall) wb |= 1u << b;
             p.s.food[(e * G + cell) * p.fs] = (fd && !wall) ? 1.0f : 0.0f;
+            if (p.meta)
+                reinterpret_cast<uint32_t *>(p.s.food)[(e * G + cell) * p.fs + 1] =
+                    (wall ? META_WALL : 0u) | (area ? META_AREA : 0u) | (META_NEVER << META_STAMP_SHIFT);
             for (int c = 0; c < p.C; ++c) {
                 p.s.phero[0][(e * G + cell) * p.ps + c] = 0.0f;
                 p.s.phero[1][(e * G + cell) * p.ps + c] = 0.0f;
@@ -290,6 +297,12 @@ __global__ void k_read_state(const KP p, const int which, const int cur, void *_
     case ANTSRL_S_ANTHILL_AREA: {
         const uint32_t *bits = which == ANTSRL_S_EXPLORED ? p.s.explored_bits
                                : which == ANTSRL_S_WALLS  ? p.s.walls_bits : p.s.area_bits;
+        if (which == ANTSRL_S_EXPLORED && p.meta) { // cell-meta layout: explored <=> the cell carries a stamp
+            const uint32_t *m = reinterpret_cast<const uint32_t *>(p.s.food) + 1;
+            for (size_t i = t0; i < EG; i += stride)
+                ((uint8_t *)dstv)[i] = (uint8_t)((m[i * p.fs] >> META_STAMP_SHIFT) != META_NEVER);
+            break;
+        }
         for (size_t i = t0; i < EG; i += stride) {
             const size_t e = i / G, g = i - e * G;
             ((uint8_t *)dstv)[i] = (uint8_t)test_bit(bits + e * p.words, (uint32_t)g);
@@ -312,6 +325,29 @@ __global__ void k_read_state(const KP p, const int which, const int cur, void *_
         break;
     default: break;
     }
+}
+
+// Measurement helper (antsrl_bench_copy): 16 bytes per lane, four independent loads in flight per lane,
+// streaming stores.
+__global__ void __launch_bounds__(256) k_copy16(uint4 *__restrict__ dst, const uint4 *__restrict__ src, const size_t n)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + 3 * stride < n; i += 4 * stride) {
+        const uint4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
+        dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
+    }
+    for (; i < n; i += stride) dst[i] = src[i];
+}
+
+hipError_t antsrl_launch_copy16(void *dst, const void *src, size_t bytes, hipStream_t st)
+{
+    const size_t n = bytes / 16;
+    if (n == 0) return hipSuccess;
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 256 * 8) blocks = 256 * 8; // 8 workgroups of 256 threads per CU
+    hipLaunchKernelGGL(k_copy16, dim3((unsigned)blocks), dim3(256), 0, st, (uint4 *)dst, (const uint4 *)src, n);
+    return hipGetLastError();
 }
 
 // host-side launchers (called from antsrl_capi.hip)

@@ -359,7 +359,7 @@ static hipError_t launch_sweep_c(const KP &p, int cur, hipStream_t st)
             if (blocks > 256 * 64) blocks = 256 * 64;
             hipLaunchKernelGGL((k_sweep0_scalar<C>), dim3((unsigned)blocks), dim3(256), 0, st, p, in, out, n);
         }
-    } else if (!getenv("ANTSRL_SWEEP_TILED")) {
+    } else if (!PROF_ENV("ANTSRL_SWEEP_TILED")) {
         const int fr = p.filter_radius;
         const int strips = (p.H + (64 - 2 * fr) - 1) / (64 - 2 * fr);
         // split the march along x into segments of >= 64 rows until the chip has ~16 waves per SIMD

@@ -265,7 +265,7 @@ static size_t update_lds_bytes(const KP &p, int threads) { return update_scratch
 
 hipError_t antsrl_launch_update(const KP &p, const double *jitter, int out_buf, hipStream_t st)
 {
-    static const bool force_loops = getenv("ANTSRL_UPDATE_LOOPS") != nullptr; // A/B: the per-phase loop kernel
+    static const bool force_loops = PROF_ENV("ANTSRL_UPDATE_LOOPS") != nullptr; // A/B: the per-phase loop kernel
     if (p.N <= 1024 && !force_loops) { // one ant per thread
         const int t1 = (p.N + 63) / 64 * 64;
         const size_t l1 = update_one_lds_bytes(p.HT, p.R, t1 / 64, p.N);

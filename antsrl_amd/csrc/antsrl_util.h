@@ -120,16 +120,21 @@ __device__ __forceinline__ void wave_lds_sync()
 #define ANTSRL_MAX_DEVICES 64 // per-device launch bookkeeping (dynamic-LDS opt-in)
 typedef float stream_f4 __attribute__((ext_vector_type(4)));
 typedef uint32_t stream_u4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void store_stream(float *dst, float v) { __builtin_nontemporal_store(v, dst); }
-__device__ __forceinline__ void store_stream(uint16_t *dst, uint16_t v) { __builtin_nontemporal_store(v, dst); }
+#ifdef ANTSRL_STORE_PLAIN // A/B (variant builds): default cache policy for the step outputs
+#define ANTSRL_NT_STORE(v, p) (*(p) = (v))
+#else
+#define ANTSRL_NT_STORE(v, p) __builtin_nontemporal_store(v, p)
+#endif
+__device__ __forceinline__ void store_stream(float *dst, float v) { ANTSRL_NT_STORE(v, dst); }
+__device__ __forceinline__ void store_stream(uint16_t *dst, uint16_t v) { ANTSRL_NT_STORE(v, dst); }
 __device__ __forceinline__ void store_stream(uint4 *dst, const uint4 &v)
 {
-    __builtin_nontemporal_store(stream_u4{v.x, v.y, v.z, v.w}, reinterpret_cast<stream_u4 *>(dst));
+    ANTSRL_NT_STORE((stream_u4{v.x, v.y, v.z, v.w}), reinterpret_cast<stream_u4 *>(dst));
 }
 __device__ __forceinline__ uint16_t bf16_bits(float v) { return __builtin_bit_cast(uint16_t, (__bf16)v); } // RNE
 __device__ __forceinline__ void store_stream(float4 *dst, const float4 &v)
 {
-    __builtin_nontemporal_store(stream_f4{v.x, v.y, v.z, v.w}, reinterpret_cast<stream_f4 *>(dst));
+    ANTSRL_NT_STORE((stream_f4{v.x, v.y, v.z, v.w}), reinterpret_cast<stream_f4 *>(dst));
 }
 
 // The smallest double T with sqrt(T) >= r, so that  sqrt(d2) < r  <=>  d2 < T  exactly (sqrt is correctly

@@ -41,28 +41,42 @@ CONFIGS = {
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 
+GUIDE_COPY_GBS = 6290.0  # float4 copy on MI355X, /opt/skills/guides/MI355X_MICROARCH.md (79 % of the spec peak)
+
+
 def measured_copy_gbs(dev, nbytes=1 << 30, reps=10):
-    """Device-to-device copy bandwidth on this box, GB/s of read + written bytes."""
+    """Device-to-device copy bandwidth on this box, GB/s of read + written bytes: the library's own
+    16-bytes-per-lane copy kernel (antsrl_bench_copy), not torch's."""
     import torch
+    from antsrl_amd import _lib
+    lib = _lib.load()
     src = torch.empty((nbytes // 4,), dtype=torch.float32, device=dev).normal_()
     dst = torch.empty_like(src)
+    st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+    def copy():
+        _lib.check(lib.antsrl_bench_copy(C.c_void_p(dst.data_ptr()), C.c_void_p(src.data_ptr()), nbytes, st), "bench_copy")
     for _ in range(2):
-        dst.copy_(src)
+        copy()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(reps):
-        dst.copy_(src)
+        copy()
     e1.record()
     e1.synchronize()
     return 2.0 * nbytes * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
 
 def algorithmic_bytes(N, W, H, Cn, K, P=49, obs_bytes=4):
-    """SURVEY.md §8(d) per env-step figure, split by the kernel that moves each term."""
+    """SURVEY.md §8(d) per env-step figure, split by the kernel that moves each term.  `move` and `perceive`
+    are the two halves of `act` on the cell-meta path (k_move: ant state r+w, actions, food RMW; k_perceive:
+    observation, agent_state and reward writes)."""
     sweep = 2 * Cn * W * H * 4 + W * H                 # pheromone read+write sweep, wall mask
-    act = N * P * K * obs_bytes + N * 60 + N * 12 + N * 8  # obs write, ant state r+w, agent_state+reward, food RMW
+    move = N * 60 + N * 8                              # ant x,y,theta f64 r+w, holding, mandibles, actions; food RMW
+    perceive = N * P * K * obs_bytes + N * 12          # obs write; agent_state + reward write
     update = N * Cn * 8                                # deposit RMW
-    return dict(sweep=sweep, act=act, update=update, total=sweep + act + update)
+    return dict(sweep=sweep, move=move, perceive=perceive, act=move + perceive, update=update,
+                total=sweep + move + perceive + update)
 
 
 class HipEvents:
@@ -126,10 +140,32 @@ def cpu_baseline(cfg_kw, make_cfg, synth_init, random_actions, budget_s=15.0):
     for t in range(steps):
         one(t)
     dt = time.perf_counter() - t0
-    return dict(value=E * cfg.n_ants * steps / dt, unit="ant-steps/s", cores=cores, kind="port",
-                sample="%d envs x %d ants, %dx%d grid, %d full steps (RLApi.step + Environment.update) "
-                       "of the same workload; oracle/antsrl_oracle.c, OpenMP over envs, %.1f s"
-                       % (E, cfg.n_ants, cfg.w, cfg.h, steps, dt))
+    out = dict(value=E * cfg.n_ants * steps / dt, unit="ant-steps/s", cores=cores, kind="port",
+               sample="%d envs x %d ants, %dx%d grid, %d full steps (RLApi.step + Environment.update) "
+                      "of the same workload; oracle/antsrl_oracle.c, OpenMP over envs, %.1f s"
+                      % (E, cfg.n_ants, cfg.w, cfg.h, steps, dt))
+    ref = reference_cpu_timing(cfg_kw.get("name"))
+    if ref:
+        out["reference"] = ref
+    return out
+
+
+def reference_cpu_timing(config_name):
+    """The unmodified reference (pure Python + numpy + scipy) cannot travel to the GPU box: it is timed in the
+    build container by tests/golden/time_reference.py; the committed record is reported beside the port."""
+    path = os.path.join(ROOT, "profiles", "r01", "reference_cpu_timing.json")
+    try:
+        rec = json.load(open(path))
+        key = [k for k in rec["cases"] if k.startswith(config_name + " ")]
+        if not key:  # c5 steps c3-shaped environments (no rocks): the c2/c3 shapes bracket it
+            return None
+        row = rec["cases"][key[0]]
+        return dict(value=row["all_core_ant_steps_per_s"], unit="ant-steps/s", cores=row["all_core_processes"],
+                    one_process=row["one_process_ant_steps_per_s"], case=key[0],
+                    where="build container, %d processes (the reference cannot travel to the GPU box)" % rec["nproc"],
+                    source="profiles/r01/reference_cpu_timing.json (tests/golden/time_reference.py)")
+    except Exception:
+        return None
 
 
 def main():
@@ -144,6 +180,9 @@ def main():
                     help="the reference's DIFFUSE_FACTOR (pheromone.py:5-10): 3x3 filter with this weight on the 8 neighbours")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--repeats", type=int, default=5, help="timed regions of --steps steps each; the median is reported")
+    ap.add_argument("--no-explicit-sweep", action="store_true",
+                    help="skip the short extra run with the per-step sweep kernel forced (explicit_sweep record)")
     ap.add_argument("--policy", default=None, choices=["random", "mlp"],
                     help="mlp: the reference's linear DQN net evaluated in-loop on the GPU (bf16 MFMA)")
     ap.add_argument("--obs-dtype", default=None, choices=["f32", "bf16"],
@@ -234,11 +273,13 @@ def main():
 
     K = args.steps
     timing = not args.no_kernel_timing
-    # per-kernel HIP events on every 4th step only: three event records between two kernels cost
+    REPEATS = max(1, args.repeats)
+    NEV = cm.TIMING_EVENTS
+    # per-kernel HIP events on every 4th step only: the event records between two kernels cost
     # ~15 us of stream idle time (rocprof trace), which would otherwise tax `value` by ~4 %
     EV_EVERY = 4
     timed_steps = list(range(0, K, EV_EVERY))
-    evs = HipEvents(4 * len(timed_steps)) if timing else None
+    evs = HipEvents(NEV * len(timed_steps)) if timing else None
 
     def barrier():
         if gather is not None:
@@ -249,68 +290,131 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    barrier()
-    t0 = time.perf_counter()
-    for t in range(K):
-        if timing and t % EV_EVERY == 0:
-            env.set_timing_events([evs.ev[4 * (t // EV_EVERY) + i].value for i in range(4)])
-        one_step(args.warmup + t)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+    # REPEATS timed regions of exactly K steps each, every one bracketed by barrier + synchronize on both
+    # sides and reduced with MAX over the ranks; `value` is the MEDIAN region (median of 5),
+    # the spread is reported beside it.  Kernel events are recorded during the last region only.
+    region_s = []
+    step_no = args.warmup
+    for rep in range(REPEATS):
+        last = rep == REPEATS - 1
+        barrier()
+        t0 = time.perf_counter()
+        for t in range(K):
+            if timing and last and t % EV_EVERY == 0:
+                env.set_timing_events([evs.ev[NEV * (t // EV_EVERY) + i].value for i in range(NEV)])
+            one_step(step_no)
+            step_no += 1
+        barrier()
+        el = time.perf_counter() - t0
+        if dist is not None:
+            tmax = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            el = float(tmax.item())
+        region_s.append(el)
+    elapsed = float(np.median(region_s))
 
     out = None
     if rank == 0:
-        ab = algorithmic_bytes(cfg.n_ants, cfg.w, cfg.h, cfg.n_phero, cfg.n_channels, obs_bytes=2 if obs_dtype == "bf16" else 4)
+        obs_bytes = 2 if obs_dtype == "bf16" else 4
+        ab = algorithmic_bytes(cfg.n_ants, cfg.w, cfg.h, cfg.n_phero, cfg.n_channels, obs_bytes=obs_bytes)
+        meta_path = bool(env.query(cm.Q_CELL_META))
+        scaled = bool(env.query(cm.Q_SCALED_UNITS))
         kern = {}
+        tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.config)
+        traffic_rec = json.load(open(tpath)) if os.path.exists(tpath) else {}
         if timing:
-            ms = np.array([[evs.elapsed_ms(4 * j + i, 4 * j + i + 1) for i in range(3)] for j in range(len(timed_steps))])
-            kern = dict(sweep=float(ms[:, 0].mean()), act=float(ms[:, 1].mean()), update=float(ms[:, 2].mean()))
-            if cm.uses_scaled_units(cfg):
+            ms = np.array([[evs.elapsed_ms(NEV * j + i, NEV * j + i + 1) for i in range(NEV - 1)]
+                           for j in range(len(timed_steps))])
+            if meta_path:
+                kern = dict(sweep=float(ms[:, 0].mean()), move=float(ms[:, 1].mean()), perceive=float(ms[:, 2].mean()),
+                            update=float(ms[:, 3].mean()))
+            else:
+                kern = dict(sweep=float(ms[:, 0].mean()), act=float((ms[:, 1] + ms[:, 2]).mean()), update=float(ms[:, 3].mean()))
+            if scaled:
                 kern.pop("sweep")  # scaled pheromone units: no sweep kernel is launched at all
             dom = max(kern, key=kern.get)
-            names = dict(sweep="k_sweep0" if cfg.filter_radius == 0 else "k_sweep_march", act="k_act",
-                         update="k_update_one" if cfg.n_ants <= 1024 else "k_update")
+            names = dict(sweep="k_sweep0" if cfg.filter_radius == 0 else "k_sweep_march", act="k_act", move="k_move",
+                         perceive="k_perceive", update="k_update_one" if cfg.n_ants <= 1024 else "k_update")
             achieved = ab[dom] * E / (kern[dom] * 1e-3) / 1e9
-            traffic = None
-            tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.config)
-            if os.path.exists(tpath):  # PMC-derived HBM bytes per launch, from a separate rocprofv3 --pmc run
-                traffic = json.load(open(tpath)).get(names[dom])
+            # PMC-derived HBM bytes per launch: NOT measured in this run (rocprofv3 --pmc needs its own passes,
+            # profiles/pmc_traffic.sh); the record names the profile it came from
+            traffic = traffic_rec.get(names[dom])
             roofline = dict(bound="hbm", kernel=names[dom], achieved=round(achieved, 1), peak=HBM_PEAK_GBS,
                             unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic,
+                            traffic_source=(traffic_rec.get("_source") if traffic is not None else None),
                             algorithmic_bytes_per_launch=ab[dom] * E,
-                            kernel_ms={names[k]: round(v, 4) for k, v in kern.items()},
-                            step_algorithmic_gbs=round(ab["total"] * E / (elapsed / K) / 1e9, 1))
+                            kernel_ms={names[k]: round(v, 4) for k, v in kern.items()})
+            step_traffic = [traffic_rec.get(names[k]) for k in kern]
+            if traffic_rec and all(v is not None for v in step_traffic):
+                # real HBM bytes of one whole step (PMC, every kernel of the step) over the measured step time
+                roofline["step_real_traffic_gbs"] = round(sum(step_traffic) / (elapsed / K) / 1e9, 1)
         else:
             roofline = dict(bound="hbm", achieved=None, peak=HBM_PEAK_GBS, unit="GB/s", frac=None, traffic=None)
         if timing and roofline.get("achieved"):
             # the spec peak next to what a plain device copy reaches on THIS box
-            # (read + write bytes of a 1 GiB float32 copy, outside the timed region)
+            # (read + write bytes of a 1 GiB copy, 16 bytes per lane, outside the timed region) and the
+            # guide's figure for the same kind of kernel
             copy_gbs = measured_copy_gbs(dev)
             roofline["measured_copy_gbs"] = round(copy_gbs, 1)
             roofline["frac_of_measured_copy"] = round(roofline["achieved"] / copy_gbs, 4)
+            roofline["guide_copy_gbs"] = GUIDE_COPY_GBS
+            roofline["frac_of_guide_copy"] = round(roofline["achieved"] / GUIDE_COPY_GBS, 4)
         value = world * E * cfg.n_ants * K / elapsed
         out = {
             "metric": "ant-steps/sec (ants x envs x steps/s), 256^2 grid" if cfg.w == 256 else "ant-steps/sec (ants x envs x steps/s)",
             "value": value, "unit": "ant-steps/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
             "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64 ant kinematics / f32 grids", "data": "synthetic",
+            "repeats": REPEATS, "ms_per_step_regions": [round(r / K * 1e3, 5) for r in region_s],
+            "ms_per_step_spread": round((max(region_s) - min(region_s)) / K * 1e3, 5),
+            "rccl_ranks": (dist.get_world_size() if dist is not None else 1),
             "config": {"workload": W_["desc"], "envs_per_gpu": E, "ants": cfg.n_ants, "grid": [cfg.w, cfg.h],
                        "pheromone_channels": cfg.n_phero, "rocks": cfg.n_rocks, "obs_channels": cfg.n_channels,
-                       "filter_radius": cfg.filter_radius, "reward": "ExplorationReward", "obs_dtype": obs_dtype,
-                       "pheromone_update": "scaled units (no per-step sweep)" if cm.uses_scaled_units(cfg)
-                       else "explicit sweep kernel",
+                       "filter_radius": cfg.filter_radius,
+                       "filter_separable": bool(env.query(cm.Q_FILTER_SEPARABLE)) if cfg.filter_radius else None,
+                       "reward": "ExplorationReward", "obs_dtype": obs_dtype,
+                       "pheromone_update": "scaled units (no per-step sweep)" if scaled else "explicit sweep kernel",
+                       "kernels": ("k_move + k_perceive (cell-meta layout, %d ants per wave) + " % env.query(cm.Q_PERCEIVE_RUN)
+                                   if meta_path else "k_act + ") + ("k_update_one" if cfg.n_ants <= 1024 else "k_update"),
                        "policy": ("linear DQN net (F+2 -> 32 -> 3+3) in-loop, bf16 MFMA" if policy is not None
                                   else "uniform random, pre-generated on device"),
                        "parallelism": "env-sharded x%d, reward/done all-gather" % world},
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(dict(N=cfg.n_ants, W=cfg.w, H=cfg.h, extra=extra),
+            out["cpu_baseline"] = cpu_baseline(dict(N=cfg.n_ants, W=cfg.w, H=cfg.h, extra=extra, name=args.config),
                                                cm.make_cfg, synth_init, random_actions)
+    if rank == 0 and out is not None and world == 1 and scaled and not args.no_explicit_sweep and policy is None:
+        # The same workload with the per-step sweep kernel forced (SURVEY.md §8(d)'s byte model counts the
+        # 2*C*W*H*4 + W*H sweep term, which the scaled units never move): a short run of its own so that the
+        # model can be checked like for like.  Outside the timed region.
+        del env
+        torch.cuda.empty_cache()
+        ex = dict(extra)
+        ex["phero_mode"] = cm.PHERO_EXPLICIT_SWEEP
+        cfg_x = cm.make_cfg(E, W_["N"], W_["W"], W_["H"], **ex)
+        env_x = BatchedAntsEnv(cfg_x, dev)
+        env_x.reset(synth_init(cfg_x, seed=1234, env_offset=rank * E))
+        for t in range(10):
+            env_x.step_update(rot[t % RING], ph[t % RING], None)
+        KX = 40
+        evx = HipEvents(NEV * (KX // EV_EVERY))
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        for t in range(KX):
+            if t % EV_EVERY == 0:
+                env_x.set_timing_events([evx.ev[NEV * (t // EV_EVERY) + i].value for i in range(NEV)])
+            env_x.step_update(rot[t % RING], ph[t % RING], None)
+        torch.cuda.synchronize(dev)
+        ms_x = (time.perf_counter() - t1) / KX * 1e3
+        sweep_ms = float(np.mean([evx.elapsed_ms(NEV * j, NEV * j + 1) for j in range(KX // EV_EVERY)]))
+        evx.destroy()
+        out["explicit_sweep"] = dict(ms_per_step=round(ms_x, 4), k_sweep0_ms=round(sweep_ms, 4),
+                                     k_sweep0_algorithmic_gbs=round(ab["sweep"] * E / (sweep_ms * 1e-3) / 1e9, 1),
+                                     step_algorithmic_gbs=round(ab["total"] * E / (ms_x * 1e-3) / 1e9, 1),
+                                     note="same workload with ANTSRL_PHERO_EXPLICIT_SWEEP: the configuration SURVEY.md "
+                                          "§8(d)'s 1 865 728 B/env-step model describes")
+        env = env_x
     if rank == 0 and out is not None:
         # device-side episode reset (antsrl_generate), outside the timed region: how long a whole-batch
         # "EnvironmentGenerator.generate" takes on the GPU

@@ -22,8 +22,10 @@
  *    failure on the calling thread;
  *  - a handle belongs to the device its workspace lives on (any number of handles per device), holds up
  *    to 65535 environments and is not thread-safe;
- *  - sizes: any grid (the per-env bit maps move from LDS to HBM scratch past ~600k cells), up to ~2400 ants
- *    per env (per-ant frames are LDS-resident); antsrl_create() returns ANTSRL_E_UNSUPPORTED beyond that.
+ *  - sizes: any grid; up to 4096 ants per env with the reference's perception shapes (2 pheromone channels,
+ *    the generator's channel order, up to 64 perceived cells: the cell-meta path, k_move + k_perceive),
+ *    ~2400 with other channel lists (k_act keeps per-ant frames in LDS); antsrl_create() returns
+ *    ANTSRL_E_UNSUPPORTED beyond that.
  */
 #ifndef ANTSRL_H
 #define ANTSRL_H
@@ -35,7 +37,7 @@
 extern "C" {
 #endif
 
-#define ANTSRL_ABI_VERSION 1
+#define ANTSRL_ABI_VERSION 2
 
 #define ANTSRL_MAX_CHANNELS 16
 #define ANTSRL_MAX_PSIDE 15                                      /* 2*radius+1 <= 15 */
@@ -257,11 +259,30 @@ int antsrl_step_update(AntsHandle *h, const int8_t *rotation, const int8_t *pher
                        uint8_t *done, void *stream);
 
 /* Measurement hook (no reference counterpart; the reference only keeps a wall-clock EMA,
- * main.py:93,132-136).  events = 4 caller-created hipEvent_t, or NULL to disable.  While set,
- * the NEXT antsrl_step_update records them on its stream: [0] before the pheromone sweep,
- * [1] after it, [2] after the act/observe kernel, [3] after the update kernel; the hook then
+ * main.py:93,132-136).  events = ANTSRL_TIMING_EVENTS caller-created hipEvent_t, or NULL to disable.
+ * While set, the NEXT antsrl_step_update records them on its stream: [0] before the pheromone sweep,
+ * [1] after it, [2] after the per-ant action kernel (k_move; equal to [1] where one kernel does both),
+ * [3] after the perception kernel (k_perceive / k_act), [4] after the update kernel; the hook then
  * clears itself. */
+#define ANTSRL_TIMING_EVENTS 5
 int antsrl_set_timing_events(AntsHandle *h, void *const *events);
+
+/* What the handle resolved its configuration to (no reference counterpart; bench.py and the tests name the
+ * kernels and byte models from it). */
+enum {
+    ANTSRL_Q_CELL_META = 0,        /* 1: k_move + k_perceive on the cell-meta layout, 0: k_act           */
+    ANTSRL_Q_SCALED_UNITS = 1,     /* 1: pheromone held in units of f0^S (no per-step sweep)              */
+    ANTSRL_Q_INTERLEAVED = 2,      /* 1: {p0, p1, food, meta} 16-byte cell records                        */
+    ANTSRL_Q_FILTER_SEPARABLE = 3, /* 1: DIFFUSE_FILTER detected as rank-1 (separable stencil march)      */
+    ANTSRL_Q_PERCEIVE_RUN = 4,     /* ants per wave of k_perceive (0 without the cell-meta path)          */
+    ANTSRL_Q_COUNT_
+};
+int antsrl_query(const AntsHandle *h, int what, long long *value);
+
+/* Measurement helper (no reference counterpart): a plain device-to-device copy of `bytes` bytes (multiple of
+ * 16, both pointers 16-byte aligned) with 16 bytes per lane, enqueued on `stream` — bench.py times it for the
+ * box's achievable read + write bandwidth next to the 8 TB/s specification. */
+int antsrl_bench_copy(void *dst, const void *src, size_t bytes, void *stream);
 
 /* Observation tensor format (no reference counterpart: the reference's perception is float64 numpy,
  * cast to float32 by torch.Tensor(state) in the agents, collect_agent_memory.py:194).
@@ -274,12 +295,6 @@ int antsrl_set_timing_events(AntsHandle *h, void *const *events);
 #define ANTSRL_OBS_F32 0
 #define ANTSRL_OBS_BF16 1
 int antsrl_set_obs_format(AntsHandle *h, int format);
-
-/* Profiling read-out (no reference counterpart).  With ANTSRL_ABLATE=32768 in the environment the
- * act kernel stamps a per-workgroup phase timeline; this copies the first n_wg records (8 x u64 each:
- * 100 MHz timestamps at entry / perception start / perception end / exit, then HW_ID and XCC_ID) to
- * host memory `dst`.  Synchronises the device. */
-int antsrl_debug_read_act_trace(unsigned long long *dst, int n_wg);
 
 /* Ants.activate_all_pheromones (environment/ants.py:86-87).  act: float [E][N][C].
  * new_deposit_strength > 0 also changes AntsCfg.deposit_strength (the dtype switch

@@ -1,0 +1,14 @@
+#!/bin/bash
+R=${GRAFT_REPO_ROOT:-/root/repo}
+cd $R
+V=$R/antsrl_amd/lib/variants
+one() { local label=$1 lib=$2; shift 2
+  env ANTSRL_LIB=$lib "$@" timeout -k 10 200 python bench.py --no-cpu-baseline --no-explicit-sweep --repeats 2 --steps 100 ${BENCH_ARGS} 2>/dev/null | python3 -c "
+import sys, json; d=json.loads(sys.stdin.read()); print('%-28s ms/step=%.4f %s' % ('$label', d['ms_per_step'], d['roofline']['kernel_ms']))" || echo "$label FAILED"
+}
+P=$R/antsrl_amd/lib/libantsrl_hip_prof.so
+one "prof" $P A=1
+for pad in 10 20 40 60; do one "lds_pad=$pad" $P ANTSRL_PRC_LDS_PAD=$pad; done
+for v in merge_masked flush3 flush3_merge; do one "$v" $V/$v.so A=1; done
+one "prof again" $P A=1
+one "legacy k_act" $P ANTSRL_LEGACY_ACT=1

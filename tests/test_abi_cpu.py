@@ -35,7 +35,7 @@ def test_header_symbols_are_exported(lib):
 
 
 def test_layout_and_version(lib):
-    assert lib.antsrl_abi_version() == 1
+    assert lib.antsrl_abi_version() == 2
     assert lib.antsrl_cfg_size() == C.sizeof(AntsCfg)
 
 
@@ -51,8 +51,9 @@ def test_workspace_bytes_and_validation(lib):
     cfg2 = make_cfg(1024, 512, 256, 256, n_rocks=8, phero_mode=PHERO_EXPLICIT_SWEEP)
     n2 = C.c_size_t()
     assert lib.antsrl_workspace_bytes(C.byref(cfg2), C.byref(n2)) == 0
-    # explicit sweep: two [cell][2] float32 pheromone buffers (ping-pong) + a separate food array
-    assert n2.value - n.value == cells * (2 * 8 + 4) - cells * 16
+    # explicit sweep: two [cell][2] float32 pheromone buffers (ping-pong) + a separate array of {food, meta}
+    # records (the cell-meta path: wall / anthill / presence bits and the explored stamp beside the food value)
+    assert n2.value - n.value == cells * (2 * 8 + 8) - cells * 16
     bad = cfg.copy()
     bad.n_phero = 9
     assert lib.antsrl_workspace_bytes(C.byref(bad), C.byref(n)) == -1
@@ -83,20 +84,31 @@ def test_create_rejects_bad_workspace(lib):
 
 
 def test_lds_budget_is_checked(lib):
-    """Grids of any size are accepted (past ~600k cells the per-env bit maps move to HBM scratch, which
-    the workspace then includes); an ant count whose per-ant frames cannot live in 160 KiB of LDS is
-    refused at create time."""
+    """Grids of any size are accepted: the reference's perception shapes take the cell-meta path (no per-env
+    bit map in LDS at all); other channel lists run k_act, whose per-env bit maps move from LDS to HBM scratch
+    past ~600k cells (the workspace then includes them).  An ant count whose per-ant state cannot live in
+    160 KiB of LDS is refused at create time."""
+    from antsrl_amd.config import CH_ANTS, CH_FOOD, CH_PHERO, CH_WALLS
     n = C.c_size_t()
     n_small = C.c_size_t()
     cfg = make_cfg(1, 64, 2048, 2048)
     assert lib.antsrl_workspace_bytes(C.byref(cfg), C.byref(n)) == 0
     h = C.c_void_p()
     assert lib.antsrl_create(C.byref(cfg), C.c_void_p(4096), n.value, C.byref(h)) == 0
+    v = C.c_longlong()
+    assert lib.antsrl_query(h, 0, C.byref(v)) == 0 and v.value == 1  # ANTSRL_Q_CELL_META
     lib.antsrl_destroy(h)
     words = 2048 * 2048 // 32
-    # 16-byte cell records + walls / anthill / explored maps + the presence and pre-step explored maps
+    assert 16 * 2048 * 2048 + 3 * 4 * words <= n.value < 16 * 2048 * 2048 + 4 * 4 * words
+    # a channel list the cell-meta path does not take: k_act with its maps in HBM scratch at this size
+    odd = [(CH_FOOD, 0), (CH_ANTS, 0), (CH_PHERO, 0), (CH_PHERO, 1), (CH_WALLS, 0)]
+    cfg_o = make_cfg(1, 64, 2048, 2048, channels=odd)
+    assert lib.antsrl_workspace_bytes(C.byref(cfg_o), C.byref(n)) == 0
+    assert lib.antsrl_create(C.byref(cfg_o), C.c_void_p(4096), n.value, C.byref(h)) == 0
+    assert lib.antsrl_query(h, 0, C.byref(v)) == 0 and v.value == 0
+    lib.antsrl_destroy(h)
     assert n.value >= 16 * 2048 * 2048 + 5 * 4 * words
-    cfg_s = make_cfg(1, 64, 512, 512)  # bit maps in LDS: no scratch maps in the workspace
+    cfg_s = make_cfg(1, 64, 512, 512, channels=odd)  # bit maps in LDS: no scratch maps in the workspace
     assert lib.antsrl_workspace_bytes(C.byref(cfg_s), C.byref(n_small)) == 0
     assert n_small.value < 16 * 512 * 512 + 4 * 4 * (512 * 512 // 32) + 65536
     cfg = make_cfg(1, 6000, 64, 64)
