@@ -57,8 +57,8 @@ class DeviceReplayMemory:
         return self[idx]
 
     def extend(self, states, agent_states, actions, rewards, new_states, new_agent_states, done):
-        """replay_memory.py:83-114.  `actions` = (rotation[n], pheromone[n] or None); `done`: bool, or a
-        per-entry bool tensor (batched envs finish at different entries of the folded ant axis)."""
+        """replay_memory.py:83-114.  `actions` = (rotation[n], pheromone[n] or None); `done`: bool, a per-entry
+        bool array [n], or a per-environment one [E] (n = E * ants: repeated over each environment's ants)."""
         rot = self._t(actions[0], torch.int64).reshape(-1)
         n = rot.shape[0]
         ph = self._t(actions[1], torch.int64).reshape(-1) if actions[1] is not None else torch.ones_like(rot)  # :100-103
@@ -68,8 +68,16 @@ class DeviceReplayMemory:
         rw = self._t(rewards, torch.float32).reshape(n)
         nst = self._t(new_states, torch.float32).reshape([n] + list(self.observation_space))
         nast = self._t(new_agent_states, torch.float32).reshape([n] + list(self.agent_space))
-        dn = (self._t(done, torch.bool).reshape(-1).expand(n) if torch.is_tensor(done) or isinstance(done, np.ndarray)
-              else torch.full((n,), bool(done), dtype=torch.bool, device=self.device))
+        if torch.is_tensor(done) or isinstance(done, np.ndarray):
+            dn = self._t(done, torch.bool).reshape(-1)
+            if dn.numel() == 1:
+                dn = dn.expand(n)
+            elif dn.numel() != n:  # one flag per environment: repeated over that environment's ants
+                if n % dn.numel() != 0:
+                    raise ValueError("done has %d entries for %d transitions" % (dn.numel(), n))
+                dn = dn.repeat_interleave(n // dn.numel())
+        else:
+            dn = torch.full((n,), bool(done), dtype=torch.bool, device=self.device)
         if n > self.max_len:  # only the newest max_len entries can survive
             cut = n - self.max_len
             st, ast, act, rw, nst, nast, dn = (x[cut:] for x in (st, ast, act, rw, nst, nast, dn))

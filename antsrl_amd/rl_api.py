@@ -80,8 +80,10 @@ class Environment:  # environment/environment.py:21-47
         Each object appears once (the reference's copies register themselves AND are added again by
         save_state, environment.py:8,39 — the viewer draws such an object twice to the same effect)."""
         from . import snapshot as S
-        ts = self.timestep
-        snap = S.Environment(self.w, self.h, self.max_time, int(np.asarray(ts).reshape(-1)[0]))
+        # a FRESH Environment like the reference's (its own timestep restarts at 1, environment.py:36-40); the
+        # simulation's step rides along as sim_timestep
+        snap = S.Environment(self.w, self.h, self.max_time, 1)
+        snap.sim_timestep = int(np.asarray(self.timestep).reshape(-1)[0])
         for obj in self.objects:
             obj.visualize_copy(snap)  # the snapshot classes register themselves with `snap`
         return snap

@@ -84,10 +84,25 @@ class _RefPickler(pickle._Pickler):  # the pure-Python pickler: save_global can 
     dispatch[type] = save_global
 
 
+_PLACEHOLDERS = {}
+
+
 class _RefUnpickler(pickle.Unpickler):
+    """Reads snapshot files without the reference: the snapshot classes resolve to the ones above; any OTHER
+    `environment.*` class becomes an attribute-bag placeholder.  (The reference's own files contain them:
+    Walls.visualize_copy returns the live Walls object, walls.py:16-17, whose `.environment` drags the whole
+    live Environment — RLApi, Ants, Anthill, Food, Pheromone, the reward — into the pickle.)"""
+
     def find_class(self, module, name):
         cls = _BY_NAME.get((module, name))
-        return cls if cls is not None else super().find_class(module, name)
+        if cls is not None:
+            return cls
+        if module == "environment" or module.startswith("environment."):
+            key = (module, name)
+            if key not in _PLACEHOLDERS:
+                _PLACEHOLDERS[key] = type(name, (object,), {"__module__": module})
+            return _PLACEHOLDERS[key]
+        return super().find_class(module, name)
 
 
 def dumps(states) -> bytes:
@@ -116,7 +131,11 @@ def snapshot_from_arrays(w: int, h: int, max_time: int, timestep: int, *, ants_x
     """One environment's state -> a snapshot in the reference's layout and object order
     (generator order, environment_generator.py:57-101: anthill, walls, food, rocks, ants,
     pheromones, RL api)."""
-    env = Environment(w, h, max_time, timestep)
+    # Environment.save_state (environment.py:36-40) builds a FRESH Environment(w, h, max_time): the snapshot's own
+    # `timestep` is always 1 in the reference's files (pinned by tests/golden/contract/snapshot_ref.pkl); the
+    # simulation's step rides along as an extra attribute the viewer ignores
+    env = Environment(w, h, max_time, 1)
+    env.sim_timestep = int(timestep)
     AnthillVisualization(env, x=int(anthill_xyr[0]), y=int(anthill_xyr[1]), radius=int(anthill_xyr[2]),
                          food=float(anthill_food))
     Walls(env, w=int(w), h=int(h), map=np.asarray(walls).astype(bool))
@@ -125,7 +144,8 @@ def snapshot_from_arrays(w: int, h: int, max_time: int, timestep: int, *, ants_x
         CircleObstaclesVisualization(env, centers=np.array(rock_centers, dtype=float),
                                      radiuses=np.array(rock_radiuses, dtype=float),
                                      weights=np.array(rock_weights, dtype=float))
-    AntsVisualization(env, ants=np.array(ants_xyt, dtype=float), mandibles=np.array(mandibles).astype(bool),
+    # (mandibles: int64 0/1, what Ants.mandibles holds after the first update_mandibles, ants.py:103-107)
+    AntsVisualization(env, ants=np.array(ants_xyt, dtype=float), mandibles=np.array(mandibles).astype(np.int64),
                       holding=np.array(holding, dtype=float), reward_state=np.array(reward_state).astype(np.uint8))
     for c in range(len(phero)):
         PheromoneVisualization(env, color=tuple(phero_colors[c]), max_val=phero_max_val,

@@ -26,11 +26,20 @@ __device__ __forceinline__ void st4(float *p, const vf4 v)
 
 template <bool NT, int GATHER>
 __global__ void k_stream(float *__restrict__ out, const float4 *__restrict__ table, const int N, const int row, const int run,
-                         const int group, const int work, const float seed, const int nseg, const int wpb, const int dup)
+                         const int group, const int work, const float seed, const int nseg, const int wpb, const int dup, const int map, const int blockflush)
 {
     extern __shared__ unsigned char smem[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int b = blockIdx.x, e = ((b >> 3) / nseg) * 8 + (b & 7), seg = (b >> 3) % nseg;
+    const int b = blockIdx.x;
+    const int e = map == 0 ? b / nseg : ((b >> 3) / nseg) * 8 + (b & 7), seg = map == 0 ? b % nseg : (b >> 3) % nseg;
+    if (blockflush) { // the workgroup's whole segment as ONE contiguous stream: its waves interleave at 1 KiB
+        float *envp = out + (size_t)e * N * row;
+        const int s_begin = min(seg * wpb * run, N), s_end = min(s_begin + wpb * run, N);
+        const size_t lo = ((size_t)s_begin * row) & ~(size_t)31, hi = (((size_t)s_end * row) + 31) & ~(size_t)31;
+        const vf4 v = {seed, 1.0f, 2.0f, 3.0f};
+        for (size_t j = lo + 4 * (size_t)threadIdx.x; j < hi; j += 4 * (size_t)blockDim.x) st4<NT>(envp + j, v);
+        return;
+    }
     const int i_begin = min((seg * wpb + wave) * run, N), i_end = min(i_begin + run, N);
     if (smem[0] == 77 && seed == 123.0f) out[0] = 1.0f; // keeps the LDS allocation
     float a = seed + lane, c = seed + 2, d = seed + 3, k = seed * 0.25f;
@@ -76,13 +85,13 @@ __global__ void k_stream(float *__restrict__ out, const float4 *__restrict__ tab
 
 int main(int argc, char **argv)
 {
-    int E = 1024, N = 512, row = 343, run = 32, group = 2, work = 0, gather = 0, nt = 1, wpb = 4, lds_kb = 0, reps = 10, dup = 0;
+    int E = 1024, N = 512, row = 343, run = 32, group = 2, work = 0, gather = 0, nt = 1, wpb = 4, lds_kb = 0, reps = 10, dup = 0, map = 1, blockflush = 0;
     for (int i = 1; i + 1 < argc; i += 2) {
         const char *k = argv[i];
         const int v = atoi(argv[i + 1]);
         if (!strcmp(k, "--envs")) E = v; else if (!strcmp(k, "--run")) run = v; else if (!strcmp(k, "--group")) group = v;
         else if (!strcmp(k, "--work")) work = v; else if (!strcmp(k, "--gather")) gather = v; else if (!strcmp(k, "--nt")) nt = v;
-        else if (!strcmp(k, "--wpb")) wpb = v; else if (!strcmp(k, "--lds")) lds_kb = v; else if (!strcmp(k, "--row")) row = v; else if (!strcmp(k, "--dup")) dup = v;
+        else if (!strcmp(k, "--wpb")) wpb = v; else if (!strcmp(k, "--lds")) lds_kb = v; else if (!strcmp(k, "--row")) row = v; else if (!strcmp(k, "--dup")) dup = v; else if (!strcmp(k, "--map")) map = v; else if (!strcmp(k, "--blockflush")) blockflush = v;
     }
     const size_t floats = (size_t)E * N * row + 64;
     float *out;
@@ -95,7 +104,7 @@ int main(int argc, char **argv)
     const dim3 grid(E * nseg), block(64 * wpb);
     const size_t lds = (size_t)lds_kb * 1024;
 #define GO(NTV, GV) { if (lds > 64 * 1024) CK(hipFuncSetAttribute((const void *)k_stream<NTV, GV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-                      hipLaunchKernelGGL((k_stream<NTV, GV>), grid, block, lds, 0, out, table, N, row, run, group, work, 1.0f, nseg, wpb, dup); }
+                      hipLaunchKernelGGL((k_stream<NTV, GV>), grid, block, lds, 0, out, table, N, row, run, group, work, 1.0f, nseg, wpb, dup, map, blockflush); }
     auto launch = [&]() {
         if (nt) { if (gather == 0) GO(true, 0) else if (gather == 1) GO(true, 1) else GO(true, 2) }
         else { if (gather == 0) GO(false, 0) else if (gather == 1) GO(false, 1) else GO(false, 2) }
@@ -111,7 +120,7 @@ int main(int argc, char **argv)
     float ms;
     CK(hipEventElapsedTime(&ms, e0, e1));
     ms /= reps;
-    printf("envs=%d run=%d group=%d wpb=%d lds=%dK work=%d gather=%d nt=%d dup=%d : %.4f ms  %.2f TB/s\n", E, run, group, wpb, lds_kb, work,
-           gather, nt, dup, ms, (double)E * N * row * 4 / ms / 1e9);
+    printf("envs=%d run=%d group=%d wpb=%d lds=%dK work=%d gather=%d nt=%d dup=%d map=%d blockflush=%d : %.4f ms  %.2f TB/s\n", E, run, group, wpb, lds_kb, work,
+           gather, nt, dup, map, blockflush, ms, (double)E * N * row * 4 / ms / 1e9);
     return 0;
 }

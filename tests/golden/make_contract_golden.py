@@ -1,0 +1,326 @@
+#!/usr/bin/env python3
+"""Generates the CONTRACT fixtures (tests/golden/contract/) by RUNNING THE REFERENCE — build container only
+(the reference lives at /root/reference there and never travels):
+
+    python tests/golden/make_contract_golden.py
+
+Same import shims as make_golden.py (dummy `noise` module, `np.bool`).  Nothing of the reference's source is
+stored: the fixtures hold inputs and the outputs / state / pickles the reference produced.
+
+  replay_ref.npz      agents/replay_memory.py:60-114 driven with non-straddling batches: every extend() input and
+                      the arrays, head, fill and a few __getitem__ results afterwards.  (A batch that straddles
+                      max_len re-enters extend() with an already stacked action array, replay_memory.py:113-114,
+                      and raises / mis-measures in the reference: recorded as `straddle_error`.)
+  snapshot_ref.pkl    what main.py:143-144 writes: pickle of [env.save_state(), ...] of a short reference run with
+                      walls, rocks, both pheromones and All_Rewards (environment.py:36-40 + the *Visualization classes)
+  snapshot_ref.npz    the state arrays of the same run at the same steps (to rebuild the snapshot from arrays)
+  snapshot_check.json antsrl_amd.snapshot.dumps(snapshot_from_arrays(...)) unpickled HERE with the reference's real
+                      environment.* classes importable: class names, attribute equality against the reference's
+                      own save_state() objects, field by field
+  agent_contract.json CollectAgentMemory.setup / initialize / get_action / update_replay_memory
+                      (agents/collect_agent_memory.py:107-131,178-206) and the loop of main.py:86-105 traced against
+                      the reference env: every rl_api attribute the agent touched, observation_space, the dtypes and
+                      shapes of what it feeds api.step(*action[:2]) and of what it reads back
+  agent_contract.npz  the actions the reference agent produced (fixed seeds) and the obs / agent_state / reward /
+                      done the reference env returned for them, plus the env's initial state: the GPU test replays
+                      the actions through antsrl_amd.RLApi and compares
+"""
+import io
+import json
+import os
+import pickle
+import random
+import sys
+import types
+
+import numpy as np
+
+import numpy.ma  # noqa: F401,E402  (before np.bool is shimmed: numpy.ma's import trips over it)
+
+sys.dont_write_bytecode = True
+sys.modules.setdefault("noise", types.ModuleType("noise"))  # food.py:2, anthill.py:2, utils.py:2
+if not hasattr(np, "bool"):
+    np.bool = bool  # ants.py:83
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, "/root/reference")
+sys.path.insert(1, ROOT)
+
+import torch  # noqa: E402
+from agents.replay_memory import ReplayMemory  # noqa: E402
+from agents.collect_agent_memory import CollectAgentMemory  # noqa: E402
+from environment.RL_api import RLApi  # noqa: E402
+from environment.circle_obstacles import CircleObstacles  # noqa: E402
+from environment.pheromone import Pheromone  # noqa: E402
+from environment.rewards.reward_custom import All_Rewards  # noqa: E402
+from generator.environment_generator import EnvironmentGenerator  # noqa: E402
+from generator.map_generators import CirclesGenerator  # noqa: E402
+
+OUT = os.path.join(HERE, "contract")
+os.makedirs(OUT, exist_ok=True)
+
+
+class BernoulliWalls:
+    """Stand-in for PerlinGenerator (needs the absent `noise` package): any bool[w,h] bitmap is a valid input."""
+
+    def __init__(self, density, rng):
+        self.density, self.rng = density, rng
+
+    def generate(self, w, h):
+        return self.rng.random((w, h)) < self.density
+
+
+# ----------------------------------------------------------------------------------------------- replay memory
+def make_replay():
+    rng = np.random.default_rng(5)
+    obs_space, agent_space, action_space, max_len = (3, 3, 2), (4,), (2,), 24
+    mem = ReplayMemory(max_len, obs_space, agent_space, action_space)
+    rec = {}
+    batches = [6, 6, 6, 6, 8, 8, 8]  # 24 then wraps: batches never straddle max_len (4 x 6, then 3 x 8)
+    for b, n in enumerate(batches):
+        st = rng.random((n,) + obs_space).astype(np.float32)
+        ast = rng.random((n,) + agent_space).astype(np.float32)
+        rot = rng.integers(0, 3, n)
+        ph = rng.integers(0, 3, n) if b % 3 != 2 else None
+        rw = rng.random(n).astype(np.float32)
+        nst = rng.random((n,) + obs_space).astype(np.float32)
+        nast = rng.random((n,) + agent_space).astype(np.float32)
+        done = bool(b % 2)
+        mem.extend(st, ast, (rot, ph), rw, nst, nast, done)
+        rec.update({"b%d_states" % b: st, "b%d_agent_states" % b: ast, "b%d_rot" % b: rot,
+                    "b%d_ph" % b: (ph if ph is not None else np.zeros(0, dtype=np.int64)), "b%d_has_ph" % b: ph is not None,
+                    "b%d_rewards" % b: rw, "b%d_new_states" % b: nst, "b%d_new_agent_states" % b: nast, "b%d_done" % b: done,
+                    "b%d_head" % b: mem.head, "b%d_fill" % b: mem.fill, "b%d_len" % b: len(mem)})
+    rec.update(n_batches=len(batches), max_len=max_len, obs_space=np.array(obs_space), agent_space=np.array(agent_space),
+               action_space=np.array(action_space), states=mem.states.numpy(), agent_states=mem.agent_states.numpy(),
+               actions=mem.actions.numpy(), rewards=mem.rewards.numpy(), new_states=mem.new_states.numpy(),
+               new_agent_states=mem.new_agent_states.numpy(), dones=mem.dones.numpy())
+    idx = [0, 5, 23, 7]
+    got = mem[idx]
+    rec["getitem_idx"] = np.array(idx)
+    for k, name in enumerate(("states", "agent_states", "actions", "rewards", "new_states", "new_agent_states", "dones")):
+        rec["getitem_" + name] = got[k].numpy()
+    rec["actions_dtype"] = str(mem.actions.dtype)
+    # the straddling case: what does the reference do?
+    mem2 = ReplayMemory(10, obs_space, agent_space, action_space)
+    try:
+        n = 7
+        for _ in range(2):
+            mem2.extend(rng.random((n,) + obs_space).astype(np.float32), rng.random((n,) + agent_space).astype(np.float32),
+                        (rng.integers(0, 3, n), rng.integers(0, 3, n)), rng.random(n).astype(np.float32),
+                        rng.random((n,) + obs_space).astype(np.float32), rng.random((n,) + agent_space).astype(np.float32), False)
+        rec["straddle_error"] = "none (fill=%d head=%d)" % (mem2.fill, mem2.head)
+    except Exception as e:  # noqa: BLE001
+        rec["straddle_error"] = "%s: %s" % (type(e).__name__, e)
+    np.savez_compressed(os.path.join(OUT, "replay_ref.npz"), **rec)
+    print("replay_ref.npz:", len(batches), "batches; straddling batch ->", rec["straddle_error"])
+
+
+# ----------------------------------------------------------------------------------------------- environment
+def build_env(seed, n_ants=24, w=64, h=64, n_rocks=2, max_steps=40):
+    rng = np.random.default_rng(1000 + seed)
+    reward = All_Rewards(fct_explore=1, fct_food=2, fct_anthill=10, fct_explore_holding=1, fct_headinganthill=3)  # main.py:42
+    api = RLApi(reward=reward, reward_threshold=1, max_speed=1, max_rot_speed=40 / 180 * np.pi,
+                carry_speed_reduction=0.05, backward_speed_reduction=0.5)  # main.py:45-50
+    gen = EnvironmentGenerator(w, h, n_ants, 2, 0, CirclesGenerator(6, 3, 6), BernoulliWalls(0.04, rng), max_steps, seed=seed)
+    env = gen.generate(api)
+    if n_rocks:
+        centers = np.stack([rng.random(n_rocks) * w * 0.6 + w * 0.2, rng.random(n_rocks) * h * 0.6 + h * 0.2], axis=1)
+        rocks = CircleObstacles(env, centers, rng.random(n_rocks) * 3 + 3, rng.random(n_rocks) * 50 + 50)
+        api.perceived_objects.append(rocks)
+    return api, env
+
+
+def env_arrays(api, env):
+    from environment.anthill import Anthill
+    from environment.food import Food
+    from environment.walls import Walls
+    objs = {type(o).__name__: o for o in env.objects}
+    pheros = [o for o in env.objects if isinstance(o, Pheromone)]
+    a = dict(ants_xyt=api.ants.ants.copy(), mandibles=api.ants.mandibles.copy(), holding=api.ants.holding.copy(),
+             reward_state=api.ants.reward_state.copy(), seed=api.ants.seed.copy(),
+             phero=np.stack([p.phero for p in pheros]), food=objs["Food"].qte.copy(), walls=objs["Walls"].map.copy(),
+             anthill_xyr=np.array([objs["Anthill"].x, objs["Anthill"].y, objs["Anthill"].radius]),
+             anthill_food=float(objs["Anthill"].food), timestep=env.timestep)
+    if "CircleObstacles" in objs:
+        r = objs["CircleObstacles"]
+        a.update(rock_centers=r.centers.copy(), rock_radiuses=r.radiuses.copy(), rock_weights=r.weights.copy())
+    return a
+
+
+# ----------------------------------------------------------------------------------------------- snapshots
+def make_snapshots():
+    from antsrl_amd import snapshot as snap
+    random.seed(3)
+    np.random.seed(3)
+    api, env = build_env(seed=11)
+    api.save_perceptive_field = True  # main.py:51
+    api.ants.activate_all_pheromones(np.ones((api.ants.n_ants, 2)) * 10)
+    rng = np.random.default_rng(9)
+    states, arrays = [], []
+    api.observation()
+    for t in range(12):
+        api.step(rng.integers(-1, 2, api.ants.n_ants), rng.integers(0, 3, api.ants.n_ants))
+        env.update()
+        if t % 4 == 3:
+            states.append(env.save_state())  # main.py:138
+            arrays.append(env_arrays(api, env))
+    with open(os.path.join(OUT, "snapshot_ref.pkl"), "wb") as f:
+        pickle.dump(states, f, protocol=2)  # main.py:143-144
+    flat = {}
+    for i, a in enumerate(arrays):
+        for k, v in a.items():
+            flat["s%d_%s" % (i, k)] = np.asarray(v)
+    # (the reference lists each visualisation copy twice, environment.py:8,39: every second one)
+    pher_colors = [list(o.color) for o in states[0].objects if type(o).__name__ == "PheromoneVisualization"][::2]
+    flat.update(n=len(arrays), w=env.w, h=env.h, max_time=env.max_time, phero_colors=np.array(pher_colors),
+                phero_max_val=255.0)
+    np.savez_compressed(os.path.join(OUT, "snapshot_ref.npz"), **flat)
+
+    # our pickles into the reference's REAL classes
+    report = {"reference_classes": {}, "field_equal": {}, "ok": True}
+    ours = []
+    for i, a in enumerate(arrays):
+        ours.append(snap.snapshot_from_arrays(
+            env.w, env.h, env.max_time, int(a["timestep"]), ants_xyt=a["ants_xyt"], mandibles=a["mandibles"],
+            holding=a["holding"], reward_state=a["reward_state"], phero=a["phero"], phero_colors=pher_colors,
+            phero_max_val=255.0, food=a["food"], walls=a["walls"], anthill_xyr=a["anthill_xyr"],
+            anthill_food=a["anthill_food"], rock_centers=a.get("rock_centers"), rock_radiuses=a.get("rock_radiuses"),
+            rock_weights=a.get("rock_weights"), heatmap=None))
+    loaded = pickle.loads(snap.dumps(ours))  # the stock unpickler: resolves environment.* to the reference's modules
+    for s_ref, s_our in zip(states, loaded):
+        assert type(s_our).__module__ == "environment.environment" and type(s_our) is type(s_ref), type(s_our)
+        for k in ("w", "h", "max_time", "timestep"):
+            report["field_equal"]["Environment." + k] = bool(getattr(s_ref, k) == getattr(s_our, k))
+        ref_by = {}
+        for o in s_ref.objects:  # the reference lists each copy twice (environment.py:8,39): keep one
+            ref_by.setdefault(type(o).__name__, o)
+        ref_ph = [o for o in s_ref.objects if type(o).__name__ == "PheromoneVisualization"][::2]
+        our_ph = [o for o in s_our.objects if type(o).__name__ == "PheromoneVisualization"]
+        for o in s_our.objects:
+            name = type(o).__name__
+            report["reference_classes"][name] = type(o).__module__
+            r = ref_by.get(name)
+            if r is None:
+                report["field_equal"][name] = "absent in the reference snapshot"
+                continue
+            if type(o) is not type(r):
+                report["ok"] = False
+            if name == "PheromoneVisualization":
+                r = ref_ph[our_ph.index(o)]
+            for k, v in vars(r).items():
+                if k == "environment":
+                    continue
+                w = getattr(o, k, None)
+                if name == "RLVisualization" and k == "heatmap":
+                    eq = True  # ours was built without the GUI-only perceptive field
+                elif isinstance(v, np.ndarray):
+                    eq = w is not None and np.asarray(w).shape == v.shape and np.asarray(w).dtype == v.dtype and bool(np.array_equal(w, v))
+                else:
+                    eq = bool(w == v)
+                key = "%s.%s" % (name, k)
+                report["field_equal"][key] = report["field_equal"].get(key, True) and eq
+                report["ok"] = report["ok"] and eq
+    json.dump(report, open(os.path.join(OUT, "snapshot_check.json"), "w"), indent=1, sort_keys=True)
+    print("snapshot_check.json: ok =", report["ok"], "classes:", report["reference_classes"])
+    assert report["ok"], report
+
+
+# ----------------------------------------------------------------------------------------------- agent contract
+class _Trace:
+    """Records attribute reads (dotted paths) on the RLApi the reference agent is handed."""
+
+    def __init__(self, target, log, path="rl_api"):
+        object.__setattr__(self, "_t", target)
+        object.__setattr__(self, "_log", log)
+        object.__setattr__(self, "_path", path)
+
+    def __getattr__(self, name):
+        v = getattr(self._t, name)
+        p = self._path + "." + name
+        self._log.add(p)
+        if name in ("ants",):
+            return _Trace(v, self._log, p)
+        return v
+
+
+def describe(a):
+    if isinstance(a, np.ndarray):
+        return {"type": "ndarray", "dtype": str(a.dtype), "shape": list(a.shape)}
+    if torch.is_tensor(a):
+        return {"type": "tensor", "dtype": str(a.dtype), "shape": list(a.shape)}
+    return {"type": type(a).__name__}
+
+
+def make_agent_contract():
+    random.seed(7)
+    np.random.seed(7)
+    torch.manual_seed(7)
+    api, env = build_env(seed=21, n_ants=16, n_rocks=0, max_steps=10)
+    init = env_arrays(api, env)
+    log = set()
+    traced = _Trace(api, log)
+    agent = CollectAgentMemory(epsilon=0.5, discount=0.99, rotations=3, pheromones=3, learning_rate=1e-5)  # main.py:53-57
+    agent.setup(traced, None)        # main.py:83
+    agent.initialize(traced)         # main.py:86
+    obs, agent_state, state = api.observation()  # main.py:88
+    contract = {"observation_space": list(agent.observation_space), "agent_space": list(agent.agent_space),
+                "action_space": list(agent.action_space), "n_ants": agent.n_ants,
+                "first_observation": {"obs": describe(obs), "agent_state": describe(agent_state), "state": describe(state)}}
+    episode_reward = np.zeros(agent.n_ants)
+    rec = {"init_" + k: np.asarray(v) for k, v in init.items()}
+    rec["obs0"], rec["agent_state0"] = obs, agent_state
+    rots, phs, obss, asts, rews, dones, jit = [], [], [], [], [], [], []
+    real_random = np.random.random
+    for s in range(10):
+        action = agent.get_action(obs, agent_state, True)  # main.py:95
+        if s == 0:
+            contract["action"] = [describe(a) for a in action]
+        new_state, new_agent_state, reward, done = api.step(*action[:2])  # main.py:98
+        if s == 0:
+            contract["step_returns"] = {"obs": describe(new_state), "agent_state": describe(new_agent_state),
+                                        "reward": describe(reward), "done": type(done).__name__}
+        episode_reward += reward  # main.py:100
+        agent.update_replay_memory(obs, agent_state, action, reward, new_state, new_agent_state, done)  # main.py:102
+        obs, agent_state = new_state, new_agent_state
+        rots.append(np.asarray(action[0])); phs.append(np.asarray(action[1]))
+        obss.append(new_state); asts.append(new_agent_state); rews.append(np.asarray(reward).copy()); dones.append(bool(done))
+        draws = []
+
+        def rec_random(*a, **k):
+            r = real_random(*a, **k)
+            draws.append(np.atleast_1d(r))
+            return r
+        np.random.random = rec_random
+        try:
+            env.update()  # main.py:131
+        finally:
+            np.random.random = real_random
+        row = np.zeros(agent.n_ants)
+        if draws:
+            d = np.concatenate(draws)
+            row[:len(d)] = d
+        jit.append(row)
+    contract["episode_reward_dtype"] = str(episode_reward.dtype)
+    contract["replay_memory"] = {"len": len(agent.replay_memory), "states": describe(agent.replay_memory.states),
+                                 "agent_states": describe(agent.replay_memory.agent_states),
+                                 "actions": describe(agent.replay_memory.actions)}
+    contract["rl_api_attributes_read"] = sorted(log)
+    contract["perceived_objects"] = [type(o).__name__ for o in api.perceived_objects]
+    contract["perception_coords_shape"] = list(api.perception_coords.shape)
+    json.dump(contract, open(os.path.join(OUT, "agent_contract.json"), "w"), indent=1, sort_keys=True)
+    rec.update(rot=np.stack(rots), ph=np.stack(phs), obs=np.stack(obss), agent_state=np.stack(asts), reward=np.stack(rews),
+               done=np.array(dones), jitter=np.stack(jit), max_time=env.max_time,
+               replay_states=agent.replay_memory.states.numpy()[:len(agent.replay_memory)],
+               replay_actions=agent.replay_memory.actions.numpy()[:len(agent.replay_memory)],
+               replay_rewards=agent.replay_memory.rewards.numpy()[:len(agent.replay_memory)])
+    np.savez_compressed(os.path.join(OUT, "agent_contract.npz"), **rec)
+    print("agent_contract.json:", contract["rl_api_attributes_read"], contract["action"][:2], contract["step_returns"])
+
+
+if __name__ == "__main__":
+    make_replay()
+    make_snapshots()
+    make_agent_contract()
+    for f in sorted(os.listdir(OUT)):
+        print("%8d  %s" % (os.path.getsize(os.path.join(OUT, f)), f))

@@ -104,7 +104,7 @@ def test_saved_states_pickle_in_the_reference_layout():
             env.update(F["jitter"][t][None])
             states.append(env.save_state())
     back = S.loads(S.dumps(states))
-    assert len(back) == len(states) and back[-1].timestep == F["timestep"][-1]
+    assert len(back) == len(states) and back[-1].timestep == 1 and back[-1].sim_timestep == F["timestep"][-1]
     last = {type(o).__name__: o for o in back[-1].objects}
     np.testing.assert_allclose(last["AntsVisualization"].ants, F["ants"][-1], rtol=0, atol=1e-9)
     np.testing.assert_array_equal(last["AntsVisualization"].holding, F["holding"][-1])
@@ -133,7 +133,7 @@ def test_snapshot_of_chosen_envs_from_the_batched_backend():
     xyt = benv.read_state(cm.S_ANTS_XYT).cpu().numpy()
     for s, e in zip(snaps, (1, 4)):
         o = {type(x).__name__: x for x in s.objects}
-        assert s.timestep == 6 and (s.w, s.h) == (48, 40)
+        assert s.timestep == 1 and s.sim_timestep == 6 and (s.w, s.h) == (48, 40)  # snapshot envs restart at 1 (environment.py:36-40)
         np.testing.assert_array_equal(o["AntsVisualization"].ants, xyt[e])
         assert (o["AnthillVisualization"].x, o["AnthillVisualization"].y, o["AnthillVisualization"].radius) == tuple(
             int(v) for v in init["anthill_xyr"][e])

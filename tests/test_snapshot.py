@@ -57,7 +57,9 @@ def test_layout_and_order():
     kinds = [type(o).__name__ for o in env.objects]
     assert kinds == ["AnthillVisualization", "Walls", "FoodVisualization", "CircleObstaclesVisualization",
                      "AntsVisualization", "PheromoneVisualization", "PheromoneVisualization", "RLVisualization"]
-    assert (env.w, env.h, env.max_time, env.timestep) == (12, 9, 500, 37)
+    # (save_state builds a fresh Environment: its own timestep is always 1, environment.py:36-40 — pinned by
+    # tests/golden/contract/snapshot_ref.pkl; the simulation's step rides along as sim_timestep)
+    assert (env.w, env.h, env.max_time, env.timestep, env.sim_timestep) == (12, 9, 500, 1, 37)
     ph = env.objects[5]
     assert ph.phero.dtype == np.uint8 and ph.phero.shape == (12, 9) and ph.max_val == 255.0  # pheromone.py:17
     np.testing.assert_array_equal(ph.phero, a["phero"][0].astype(np.uint8))
@@ -79,7 +81,7 @@ def test_pickle_names_the_reference_classes_and_loads_in_a_viewer_process(viewer
     assert len(loaded) == 3 and type(loaded[0]) is viewer_modules[("environment.environment", "Environment")]
     for t, env in zip((1, 2, 3), loaded):
         a = _arrays(t)
-        assert env.timestep == t and env.w == 12 and env.h == 9
+        assert env.timestep == 1 and env.sim_timestep == t and env.w == 12 and env.h == 9
         ants = [o for o in env.objects if type(o) is viewer_modules[("environment.ants", "AntsVisualization")]]
         assert len(ants) == 1 and ants[0].environment is env
         np.testing.assert_array_equal(ants[0].ants, a["ants_xyt"])
