@@ -138,10 +138,16 @@ class BatchedAntsEnv:
             _lib.check(self.lib.antsrl_reset(self._h, C.byref(ai), self._stream()), "reset")
         self._keep = t  # inputs must outlive the enqueued reset kernels
 
-    def generate(self, gen=None, episode_seed: int = 0) -> None:
+    def generate(self, gen=None, episode_seed: int = 0, walls=None) -> None:
         """Device-side episode generation (antsrl_generate): no host arrays, no upload.  With
-        gen.auto_reset, step_update() regenerates all envs after the step that reported done."""
+        gen.auto_reset, step_update() regenerates all envs after the step that reported done.
+        walls (uint8 / bool [E, W, H], for gen.wall_kind == WALLS_INPUT): the bitmaps a walls_generator returned."""
         g = gen if gen is not None else cfgmod.make_gen()
+        if walls is not None:
+            c = self.cfg
+            self._gen_walls = self._dev(np.asarray(walls).astype(np.uint8) if not torch.is_tensor(walls) else walls,
+                                        torch.uint8, (c.n_envs, c.w, c.h))
+            g.walls_input = self._gen_walls.data_ptr()  # kept alive: auto-reset reads it again
         with torch.cuda.device(self.device):
             _lib.check(self.lib.antsrl_generate(self._h, C.byref(g), int(episode_seed), self._stream()), "generate")
 

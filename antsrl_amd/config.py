@@ -98,19 +98,25 @@ class AntsGen(C.Structure):
     _fields_ = [("wall_density", C.c_double), ("n_food_discs", C.c_int32), ("food_rmin", C.c_int32),
                 ("food_rmax", C.c_int32), ("auto_reset", C.c_int32), ("wall_kind", C.c_int32),
                 ("perlin_octaves", C.c_int32), ("perlin_scale", C.c_double), ("perlin_persistence", C.c_double),
-                ("perlin_lacunarity", C.c_double)]
+                ("perlin_lacunarity", C.c_double), ("rng_kind", C.c_int32), ("_pad", C.c_int32),
+                ("walls_input", C.c_void_p)]
 
 
-WALLS_BERNOULLI, WALLS_PERLIN = 0, 1
+WALLS_BERNOULLI, WALLS_PERLIN, WALLS_INPUT = 0, 1, 2
+RNG_COUNTER, RNG_REFERENCE = 0, 1
 
 
 def make_gen(wall_density=0.05, n_food_discs=20, food_rmin=5, food_rmax=10, auto_reset=False, walls="bernoulli",
-             perlin_scale=22.0, perlin_octaves=2, perlin_persistence=0.5, perlin_lacunarity=2.0) -> AntsGen:
+             perlin_scale=22.0, perlin_octaves=2, perlin_persistence=0.5, perlin_lacunarity=2.0, rng="counter",
+             walls_input_ptr=None) -> AntsGen:
     """Defaults: main.py:74 (CirclesGenerator(20, 5, 10)); walls 5 % independent cells.
-    walls="perlin": PerlinGenerator(scale, density=wall_density, octaves, persistence, lacunarity), main.py:75."""
-    kind = {"bernoulli": WALLS_BERNOULLI, "perlin": WALLS_PERLIN}[walls]
+    walls="perlin": PerlinGenerator(scale, density=wall_density, octaves, persistence, lacunarity), main.py:75;
+    walls="input": the caller's bitmap (walls_input_ptr: device pointer to uint8 [E][W][H]).
+    rng="reference": the reference's own MT19937 streams (ANTSRL_RNG_REFERENCE)."""
+    kind = {"bernoulli": WALLS_BERNOULLI, "perlin": WALLS_PERLIN, "input": WALLS_INPUT}[walls]
     return AntsGen(wall_density, n_food_discs, food_rmin, food_rmax, 1 if auto_reset else 0, kind,
-                   int(perlin_octaves), float(perlin_scale), float(perlin_persistence), float(perlin_lacunarity))
+                   int(perlin_octaves), float(perlin_scale), float(perlin_persistence), float(perlin_lacunarity),
+                   {"counter": RNG_COUNTER, "reference": RNG_REFERENCE}[rng], 0, walls_input_ptr)
 
 
 class AntsInit(C.Structure):

@@ -179,6 +179,7 @@ static size_t carve(const AntsCfg *c, DState *s, unsigned char *base)
     d.timestep = (int32_t *)take(4 * E);
     d.reward_primed = (uint8_t *)take(E);
     d.gen_discs = (int32_t *)take(4 * E * ANTSRL_MAX_FOOD_DISCS * 3);
+    d.gen_perlin = (int32_t *)take(4 * E * 2);
     if (s) *s = d;
     return off;
 }
@@ -355,8 +356,20 @@ extern "C" int antsrl_generate(AntsHandle *h, const AntsGen *gen, uint64_t episo
             !(gen->perlin_scale > 0.0) || !(gen->perlin_persistence > 0.0) || !(gen->perlin_lacunarity > 0.0))
             return fail(ANTSRL_E_INVALID, "bad Perlin wall parameters (density in [-1, 1], 1..8 octaves, positive "
                                           "scale / persistence / lacunarity)");
+    } else if (gen->wall_kind == ANTSRL_WALLS_INPUT) {
+        if (!gen->walls_input) return fail(ANTSRL_E_INVALID, "ANTSRL_WALLS_INPUT needs AntsGen.walls_input");
     } else {
         return fail(ANTSRL_E_INVALID, "bad wall_kind %d", gen->wall_kind);
+    }
+    if (gen->rng_kind != ANTSRL_RNG_COUNTER && gen->rng_kind != ANTSRL_RNG_REFERENCE)
+        return fail(ANTSRL_E_INVALID, "bad rng_kind %d", gen->rng_kind);
+    if (gen->rng_kind == ANTSRL_RNG_REFERENCE) {
+        if (gen->wall_kind == ANTSRL_WALLS_BERNOULLI && gen->wall_density != 0.0)
+            return fail(ANTSRL_E_UNSUPPORTED, "the reference has no Bernoulli walls generator: with ANTSRL_RNG_REFERENCE use "
+                                              "ANTSRL_WALLS_PERLIN, ANTSRL_WALLS_INPUT or wall_density 0");
+        // np.random.seed(seed * 5) takes 32 bits (environment_generator.py:55); auto-reset adds one per episode
+        if ((episode_seed + (uint64_t)h->p.E + 65536u) * 5u > 0xFFFFFFFFull)
+            return fail(ANTSRL_E_INVALID, "ANTSRL_RNG_REFERENCE: (episode_seed + n_envs) * 5 must stay below 2^32");
     }
     h->gen = *gen;
     h->has_gen = true;
@@ -535,7 +548,9 @@ extern "C" int antsrl_step_update(AntsHandle *h, const int8_t *rotation, const i
     rc = do_update(h, wall_jitter, st, true, fuse);
     if (timed) (void)hipEventRecord(h->ev[4], st);
     if (rc == ANTSRL_OK && was_done && h->has_gen && h->gen.auto_reset)
-        rc = do_generate(h, h->episode_seed + 1, st); // next episode, like main.py:69-79 does per episode
+        // next episode, like main.py:69-79 does per episode (reference streams: env e takes seed + e, so the next
+        // episode starts E seeds further)
+        rc = do_generate(h, h->episode_seed + (h->gen.rng_kind == ANTSRL_RNG_REFERENCE ? (uint64_t)h->p.E : 1u), st);
     return rc;
 }
 

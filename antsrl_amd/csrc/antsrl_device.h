@@ -77,6 +77,8 @@ struct DState {
     int32_t *timestep;                       // [E]
     uint8_t *reward_primed;                  // [E]
     int32_t *gen_discs;                      // [E][ANTSRL_MAX_FOOD_DISCS][3] food discs of the device generator
+    int32_t *gen_perlin;                     // [E][2] PerlinGenerator's offsets (ANTSRL_RNG_REFERENCE: drawn from the
+                                             //        environment's Python stream by k_gen_mt)
     // cell-meta layout only (KP::meta)
     uint8_t *primed_cur;                     // [E]   reward_primed as the current observation must see it
 };

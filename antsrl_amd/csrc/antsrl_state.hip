@@ -179,6 +179,151 @@ __device__ double perlin_at(long cx, long cy, long ox, long oy, const AntsGen &g
     return (double)(total / mx);
 }
 
+
+// ---- ANTSRL_RNG_REFERENCE: the reference's own random streams -----------------------------------------------
+// EnvironmentGenerator.generate seeds Python's `random` with `seed` and numpy's legacy generator with `seed * 5`
+// (environment_generator.py:53-55): two MT19937 generators (Matsumoto & Nishimura 1998, as published: state of
+// 624 words, twist with 0x9908b0df, tempering 11 / 7 & 0x9d2c5680 / 15 & 0xefc60000 / 18) that differ in their
+// seeding — Python: init_by_array over the 32-bit limbs of the integer, numpy: init_genrand(seed) — and share the
+// 53-bit double (a >> 5, b >> 6) -> (a * 2^26 + b) / 2^53.  One wave per environment; lane 0 advances the
+// generators (the recurrence is sequential), all lanes turn a block's outputs into doubles and scatter them.
+#define MT_N 624
+#define MT_M 397
+__device__ __forceinline__ void mt_init_genrand(uint32_t *mt, uint32_t s)
+{
+    mt[0] = s;
+    for (int i = 1; i < MT_N; ++i) mt[i] = 1812433253u * (mt[i - 1] ^ (mt[i - 1] >> 30)) + (uint32_t)i;
+}
+__device__ __forceinline__ void mt_init_by_array(uint32_t *mt, const uint32_t *key, int len)
+{
+    mt_init_genrand(mt, 19650218u);
+    int i = 1, j = 0;
+    for (int k = MT_N > len ? MT_N : len; k; --k) {
+        mt[i] = (mt[i] ^ ((mt[i - 1] ^ (mt[i - 1] >> 30)) * 1664525u)) + key[j] + (uint32_t)j;
+        ++i; ++j;
+        if (i >= MT_N) { mt[0] = mt[MT_N - 1]; i = 1; }
+        if (j >= len) j = 0;
+    }
+    for (int k = MT_N - 1; k; --k) {
+        mt[i] = (mt[i] ^ ((mt[i - 1] ^ (mt[i - 1] >> 30)) * 1566083941u)) - (uint32_t)i;
+        ++i;
+        if (i >= MT_N) { mt[0] = mt[MT_N - 1]; i = 1; }
+    }
+    mt[0] = 0x80000000u;
+}
+// next block of 624 outputs: twist in place, then tempered values into out[]
+__device__ __forceinline__ void mt_next_block(uint32_t *mt, uint32_t *out)
+{
+    for (int k = 0; k < MT_N; ++k) {
+        const uint32_t y = (mt[k] & 0x80000000u) | (mt[(k + 1) % MT_N] & 0x7fffffffu);
+        mt[k] = mt[(k + MT_M) % MT_N] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+    }
+    for (int k = 0; k < MT_N; ++k) {
+        uint32_t y = mt[k];
+        y ^= y >> 11;
+        y ^= (y << 7) & 0x9d2c5680u;
+        y ^= (y << 15) & 0xefc60000u;
+        y ^= y >> 18;
+        out[k] = y;
+    }
+}
+__device__ __forceinline__ double mt_double(uint32_t a, uint32_t b)
+{
+    return ((double)(a >> 5) * 67108864.0 + (double)(b >> 6)) * (1.0 / 9007199254740992.0);
+}
+
+// per environment: everything EnvironmentGenerator.generate draws (environment_generator.py:52-94)
+__global__ void __launch_bounds__(64) k_gen_mt(const KP p, const AntsGen g, const uint64_t seed0)
+{
+    __shared__ uint32_t mt[MT_N], out[MT_N];
+    __shared__ int s_ar;
+    const int e = blockIdx.x, lane = threadIdx.x;
+    const int W = p.W, H = p.H, N = p.N, R = p.R, m = W < H ? W : H;
+    const uint64_t seed = seed0 + (uint64_t)e;
+    const size_t eN = (size_t)e * N;
+
+    // ---- Python stream: anthill (:60-63), PerlinGenerator's offsets (map_generators.py:19-20), food circles (:37-39)
+    if (lane == 0) {
+        uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+        mt_init_by_array(mt, key, key[1] ? 2 : 1); // random.seed(int): the limbs of abs(seed), least significant first
+        mt_next_block(mt, out);
+        int pos = 0;
+        auto next32 = [&]() -> uint32_t {
+            if (pos == MT_N) { mt_next_block(mt, out); pos = 0; }
+            return out[pos++];
+        };
+        auto rnd = [&]() -> double { const uint32_t a = next32(), b = next32(); return mt_double(a, b); };
+        p.s.anthill_xyr[3 * e + 0] = (int)(rnd() * W * 0.5 + W * 0.25);
+        p.s.anthill_xyr[3 * e + 1] = (int)(rnd() * H * 0.5 + H * 0.25);
+        const int ar = (int)(rnd() * m * 0.05 + m * 0.05);
+        p.s.anthill_xyr[3 * e + 2] = ar;
+        s_ar = ar;
+        if (g.wall_kind == ANTSRL_WALLS_PERLIN)
+            for (int k = 0; k < 2; ++k) { // random.randint(-10000, 10000) = -10000 + _randbelow(20001): 15-bit draws, rejection
+                uint32_t r;
+                do r = next32() >> 17; while (r >= 20001u);
+                p.s.gen_perlin[2 * e + k] = (int)r - 10000;
+            }
+        for (int d = 0; d < g.n_food_discs; ++d) {
+            const int rad = (int)(rnd() * (g.food_rmax - g.food_rmin) + g.food_rmin);
+            int32_t *dd = p.s.gen_discs + ((size_t)e * ANTSRL_MAX_FOOD_DISCS + d) * 3;
+            dd[0] = rad;
+            dd[1] = (int)(rnd() * (W - 2 * rad) + rad);
+            dd[2] = (int)(rnd() * (H - 2 * rad) + rad);
+        }
+        p.s.anthill_food[e] = 0.0;
+        p.s.timestep[e] = 1; // environment.py:27
+        p.s.reward_primed[e] = 0;
+        mt_init_genrand(mt, (uint32_t)(seed * 5u)); // np.random.seed(seed * 5)
+    }
+    __syncthreads();
+    // ---- numpy stream, doubles in draw order: rock centres [R][2], radiuses [R], weights [R] (:77-85, the evident
+    // intent of the broken branch), then ants_angle [N], ants_dist [N], ants_t [N] (:87-91), Ants.seed [N] (ants.py:41)
+    const int n_dbl = 4 * R + 4 * N;
+    for (int base = 0; base < n_dbl; base += MT_N / 2) {
+        if (lane == 0) mt_next_block(mt, out);
+        __syncthreads();
+        for (int j = lane; j < MT_N / 2 && base + j < n_dbl; j += 64) {
+            const double u = mt_double(out[2 * j], out[2 * j + 1]);
+            int d = base + j;
+            if (d < 2 * R) {
+                const int r = d >> 1;
+                if (d & 1) p.s.rock_cy[(size_t)e * R + r] = u * (H * 0.25) + H * 0.25;
+                else p.s.rock_cx[(size_t)e * R + r] = u * (W * 0.75) + W * 0.25;
+                continue;
+            }
+            d -= 2 * R;
+            if (d < R) { p.s.rock_r[(size_t)e * R + d] = u * 5 + 5; continue; }
+            d -= R;
+            if (d < R) { p.s.rock_w[(size_t)e * R + d] = u * 50 + 50; continue; }
+            d -= R;
+            const int arr = d / N, a = d - arr * N;
+            if (arr == 0) p.s.prev_x[eN + a] = u * 2 * PI_D;                  // ants_angle (scratch until the ants are placed)
+            else if (arr == 1) p.s.prev_y[eN + a] = u * (double)s_ar * 0.8;   // ants_dist
+            else if (arr == 2) p.s.theta[eN + a] = u * 2 * PI_D;              // ants_t
+            else p.s.seed[eN + a] = (float)u;                                 // Ants.seed
+        }
+        __syncthreads();
+    }
+    // ---- ants around the anthill (:89-90), then Ants.__init__ (ants.py:18-41)
+    const double ax = (double)p.s.anthill_xyr[3 * e + 0], ay = (double)p.s.anthill_xyr[3 * e + 1];
+    for (int a = lane; a < N; a += 64) {
+        const size_t i = eN + a;
+        const double ang = p.s.prev_x[i], dist = p.s.prev_y[i];
+        const double x = warp_coord(cos(ang) * dist + ax, (double)W);
+        const double y = warp_coord(sin(ang) * dist + ay, (double)H);
+        p.s.x[i] = x; p.s.y[i] = y;
+        p.s.prev_x[i] = x; p.s.prev_y[i] = y;
+        p.s.holding[i] = 0.0f; p.s.prev_holding[i] = 0.0f;
+        p.s.mandibles[i] = 0; p.s.reward_state[i] = 0;
+        p.s.dirty_cell[i] = -1;
+        p.s.walldep_cell[i] = -1;
+        for (int c = 0; c < p.C; ++c) p.s.activation[i * p.C + c] = 0.0f;
+        const double dx = x - ax, dy = y - ay;
+        p.s.prev_dist[i] = sqrt(dx * dx + dy * dy); // reward_custom.py:77
+    }
+}
+
 // per 32-cell word: anthill area (anthill.py:28-33), walls cleared on it (:66-67), food discs zeroed
 // on walls (:71-72), empty pheromone and explored map
 __global__ void k_gen_cells(const KP p, const AntsGen g, const uint64_t seed)
@@ -189,18 +334,20 @@ __global__ void k_gen_cells(const KP p, const AntsGen g, const uint64_t seed)
         const size_t e = i / p.words, w = i - e * p.words;
         const long ax = p.s.anthill_xyr[3 * e + 0], ay = p.s.anthill_xyr[3 * e + 1], ar = p.s.anthill_xyr[3 * e + 2];
         const int32_t *discs = p.s.gen_discs + e * ANTSRL_MAX_FOOD_DISCS * 3;
-        // PerlinGenerator.generate: random.randint(-10000, 10000) twice (map_generators.py:19-20)
-        const long pox = (long)(gen_u01(seed, (uint32_t)e, GEN_WALL_OFFSET, 0) * 20001.0) - 10000;
-        const long poy = (long)(gen_u01(seed, (uint32_t)e, GEN_WALL_OFFSET, 1) * 20001.0) - 10000;
+        // PerlinGenerator.generate: random.randint(-10000, 10000) twice (map_generators.py:19-20); with the
+        // reference's streams k_gen_mt drew them from the environment's Python generator
+        const bool ref_rng = g.rng_kind == ANTSRL_RNG_REFERENCE;
+        const long pox = ref_rng ? (long)p.s.gen_perlin[2 * e + 0] : (long)(gen_u01(seed, (uint32_t)e, GEN_WALL_OFFSET, 0) * 20001.0) - 10000;
+        const long poy = ref_rng ? (long)p.s.gen_perlin[2 * e + 1] : (long)(gen_u01(seed, (uint32_t)e, GEN_WALL_OFFSET, 1) * 20001.0) - 10000;
         uint32_t wb = 0, ab = 0;
         for (int b = 0; b < 32; ++b) {
             const size_t cell = w * 32 + b;
             if (cell >= G) break;
             const long x = (long)(cell / p.H), y = (long)(cell % p.H);
             const bool area = ar >= 0 && (ax - x) * (ax - x) + (ay - y) * (ay - y) <= ar * ar;
-            const bool wall = !area && (g.wall_kind == ANTSRL_WALLS_PERLIN
-                                            ? perlin_at(x, y, pox, poy, g) > g.wall_density
-                                            : gen_u01(seed, (uint32_t)e, GEN_WALLS, (uint32_t)cell) < g.wall_density);
+            const bool wall = !area && (g.wall_kind == ANTSRL_WALLS_PERLIN  ? perlin_at(x, y, pox, poy, g) > g.wall_density
+                                        : g.wall_kind == ANTSRL_WALLS_INPUT ? g.walls_input[e * G + cell] != 0
+                                        : g.wall_density > 0.0 && gen_u01(seed, (uint32_t)e, GEN_WALLS, (uint32_t)cell) < g.wall_density);
             bool fd = false;
             for (int d = 0; d < g.n_food_discs; ++d) {
                 const long rad = discs[3 * d], dx = discs[3 * d + 1] - x, dy = discs[3 * d + 2] - y;
@@ -364,6 +511,11 @@ hipError_t antsrl_launch_reset(const KP &p, const AntsInit *in, hipStream_t st)
 
 hipError_t antsrl_launch_generate(const KP &p, const AntsGen &g, uint64_t seed, hipStream_t st)
 {
+    if (g.rng_kind == ANTSRL_RNG_REFERENCE) { // the reference's MT19937 streams: one wave per environment
+        hipLaunchKernelGGL(k_gen_mt, dim3(p.E), dim3(64), 0, st, p, g, seed);
+        hipLaunchKernelGGL(k_gen_cells, dim3(grid_for((size_t)p.E * p.words)), dim3(256), 0, st, p, g, seed);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(k_gen_env, dim3((p.E + 255) / 256), dim3(256), 0, st, p, g, seed);
     hipLaunchKernelGGL(k_gen_cells, dim3(grid_for((size_t)p.E * p.words)), dim3(256), 0, st, p, g, seed);
     hipLaunchKernelGGL(k_gen_ants, dim3(grid_for((size_t)p.E * p.N)), dim3(256), 0, st, p, seed);

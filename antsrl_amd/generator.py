@@ -234,21 +234,32 @@ class DeviceEnvironmentGenerator(EnvironmentGenerator):
     Walls are independent cells of the given density, or — walls_generator=PerlinGenerator(...), as in
     main.py:75 — that generator's Perlin caves drawn on the device (its scale / density / octaves /
     persistence / lacunarity; the same noise function as PerlinGenerator.generate on the host); food is
-    `n_food_discs` discs of radius food_rmin..food_rmax (CirclesGenerator's family, main.py:74).  Random
-    streams are counter-based, NOT the reference's MT19937: same distribution, different maps.
-    auto_reset=True regenerates every env (seed+1, seed+2, ...) right after the update of the step that
-    reported done."""
+    `n_food_discs` discs of radius food_rmin..food_rmax (CirclesGenerator's family, main.py:74).
+    reference_streams=False: counter-based random streams — the reference's distributions, different maps.
+    reference_streams=True: the reference's own MT19937 streams on the device (ANTSRL_RNG_REFERENCE): env e is
+    EnvironmentGenerator(seed=seed + e).generate of the reference — same anthill, food discs, rocks, ants and
+    per-ant seeds for equal seeds; walls_generator is then a PerlinGenerator (drawn on the device), None (no walls)
+    or any object with .generate(w, h) -> bool[w, h] that does not use the global random streams (called on the
+    host once per env, uploaded as bitmaps).
+    auto_reset=True regenerates every env (the next seeds) right after the update of the step that reported done."""
 
     def __init__(self, w, h, n_ants, n_pheromones, n_rocks, max_steps, seed=0, n_envs=1, wall_density=0.05,
-                 n_food_discs=20, food_rmin=5, food_rmax=10, auto_reset=False, walls_generator=None):
+                 n_food_discs=20, food_rmin=5, food_rmax=10, auto_reset=False, walls_generator=None,
+                 reference_streams=False):
         super().__init__(w, h, n_ants, n_pheromones, n_rocks, None, walls_generator, max_steps, seed=seed, n_envs=n_envs)
+        rng = "reference" if reference_streams else "counter"
+        self.walls_bitmaps = None
         if walls_generator is None:
-            self.gen = cm.make_gen(wall_density, n_food_discs, food_rmin, food_rmax, auto_reset)
+            self.gen = cm.make_gen(0.0 if reference_streams else wall_density, n_food_discs, food_rmin, food_rmax,
+                                   auto_reset, rng=rng)
         elif isinstance(walls_generator, PerlinGenerator):
             g = walls_generator
             self.gen = cm.make_gen(g.density, n_food_discs, food_rmin, food_rmax, auto_reset, walls="perlin",
                                    perlin_scale=g.scale, perlin_octaves=g.octaves, perlin_persistence=g.persistence,
-                                   perlin_lacunarity=g.lacunarity)
+                                   perlin_lacunarity=g.lacunarity, rng=rng)
+        elif reference_streams:
+            self.walls_bitmaps = np.stack([np.asarray(walls_generator.generate(w, h)).astype(np.uint8) for _ in range(n_envs)])
+            self.gen = cm.make_gen(0.0, n_food_discs, food_rmin, food_rmax, auto_reset, walls="input", rng=rng)
         else:
             raise TypeError("the device generator draws Bernoulli walls (walls_generator=None) or a PerlinGenerator's")
 
@@ -269,7 +280,7 @@ class DeviceEnvironmentGenerator(EnvironmentGenerator):
         rl_api._pending = (dict(n_envs=self.n_envs, n_ants=self.n_ants, w=self.w, h=self.h,
                                 n_phero=self.n_pheromones, n_rocks=self.n_rocks, max_time=self.max_steps,
                                 max_hold=5.0, phero_max_val=255.0, deposit_strength=1.0),
-                           ("device", self.gen, int(self.seed or 0)))
+                           ("device", self.gen, int(self.seed or 0), self.walls_bitmaps))
         mask = None if self.perception_mask is None else np.asarray(self.perception_mask)
         rl_api.setup_perception(mask.shape[0] // 2 if mask is not None else 3, perceived, mask, self.perception_shift)
         return env

@@ -409,8 +409,8 @@ class RLApi(EnvObject):  # environment/RL_api.py:22-204
                           reward_kind=self.reward.kind, reward_threshold=float(self.reward_threshold),
                           **self.reward.weights(), **kw)
         self._backend = BatchedAntsEnv(cfg)
-        if isinstance(init, tuple):  # ("device", AntsGen, episode_seed): generated on the GPU
-            self._backend.generate(init[1], init[2])
+        if isinstance(init, tuple):  # ("device", AntsGen, episode_seed[, walls bitmaps]): generated on the GPU
+            self._backend.generate(init[1], init[2], walls=init[3] if len(init) > 3 else None)
         else:
             self._backend.reset(init)
         self.environment._backend = self._backend

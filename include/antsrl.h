@@ -156,6 +156,20 @@ typedef struct AntsInit {
                                     lacunarity) > wall_density, per-env offsets ox, oy uniform in
                                     [-10000, 10000]; improved Perlin noise restated from the published
                                     algorithm in float32 (the `noise` package is absent: unpinned) */
+#define ANTSRL_WALLS_INPUT 2     /* the caller's bitmap (AntsGen.walls_input, uint8 [E][W][H], device memory): what any
+                                    walls_generator.generate(w, h) returned; cleared on the anthill area
+                                    like environment_generator.py:66-67 */
+/* random streams of the device generator */
+#define ANTSRL_RNG_COUNTER 0     /* counter-based, keyed on (episode_seed, env, item): same distributions as the
+                                    reference's generator, different maps (the oracle restates it) */
+#define ANTSRL_RNG_REFERENCE 1   /* the reference's own streams: env e is drawn like EnvironmentGenerator(seed =
+                                    episode_seed + e).generate — random.seed(seed) / np.random.seed(seed * 5)
+                                    (environment_generator.py:53-55), i.e. two MT19937 generators per env with
+                                    Python's and numpy's seeding and 53-bit doubles, consumed in the reference's order
+                                    (anthill :60-63, PerlinGenerator's two randints map_generators.py:19-20,
+                                    CirclesGenerator :37-39, rocks :77-85, ants :87-91, Ants.seed ants.py:41): equal
+                                    seeds give the reference's anthill, food discs, ants and seeds bit for bit.
+                                    Walls: ANTSRL_WALLS_PERLIN or ANTSRL_WALLS_INPUT.  (episode_seed + E) * 5 < 2^32. */
 typedef struct AntsGen {
     double wall_density;   /* Bernoulli: probability of a wall cell; Perlin: PerlinGenerator.density (threshold) */
     int32_t n_food_discs;  /* CirclesGenerator.n_circles, main.py:74 uses 20 (<= ANTSRL_MAX_FOOD_DISCS) */
@@ -167,6 +181,9 @@ typedef struct AntsGen {
     double perlin_scale;         /* 22.0 */
     double perlin_persistence;   /* 0.5 */
     double perlin_lacunarity;    /* 2.0 */
+    int32_t rng_kind;            /* ANTSRL_RNG_* */
+    int32_t _pad;
+    const uint8_t *walls_input;  /* ANTSRL_WALLS_INPUT: uint8 [E][W][H] device memory, else NULL */
 } AntsGen;
 
 typedef struct AntsHandle AntsHandle;

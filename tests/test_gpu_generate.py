@@ -198,3 +198,71 @@ def test_device_generator_takes_the_reference_walls_generator():
     assert walls.shape == (3, 96, 80) and 0 < walls.mean() < 0.3
     with pytest.raises(TypeError):
         DeviceEnvironmentGenerator(32, 32, 4, 2, 0, max_steps=5, walls_generator=object())
+
+
+def _bernoulli_walls(seed, w, h, density=0.05):
+    return np.random.default_rng(1000 + seed).random((w, h)) < density
+
+
+@pytest.mark.parametrize("walls_kind", ["input", "perlin", "none"])
+def test_generate_with_the_reference_streams_equals_the_host_generator(walls_kind):
+    """ANTSRL_RNG_REFERENCE: env e is drawn like the reference's EnvironmentGenerator(seed = episode_seed + e) —
+    Python's and numpy's MT19937 streams on the device.  The host generator (antsrl_amd.generator, pinned to the
+    reference's initial states by tests/test_generator.py, itself running on Python's / numpy's own MT19937) draws
+    the same episodes: anthill, walls, food, rocks, seeds bit for bit, ant positions to the last bits of cos / sin."""
+    import torch
+    from antsrl_amd import config as cm
+    from antsrl_amd.batched import BatchedAntsEnv
+    from antsrl_amd.generator import CirclesGenerator, EmptyGenerator, EnvironmentGenerator, PerlinGenerator
+    E, N, W, H, R, seed = 5, 37, 96, 64, 3, 4242
+
+    class Input:
+        def __init__(self):
+            self.k = 0
+
+        def generate(self, w, h):
+            self.k += 1
+            return _bernoulli_walls(seed + self.k - 1, w, h)
+    wg = {"input": Input(), "perlin": PerlinGenerator(scale=9.0, density=0.15), "none": EmptyGenerator()}[walls_kind]
+    host = EnvironmentGenerator(W, H, N, 2, R, CirclesGenerator(7, 3, 8), wg, 100, seed=seed, n_envs=E).draw()
+    cfg = cm.make_cfg(E, N, W, H, n_rocks=R, deposit_strength=256.0)
+    env = BatchedAntsEnv(cfg)
+    if walls_kind == "input":
+        gen = cm.make_gen(0.0, 7, 3, 8, walls="input", rng="reference")
+        env.generate(gen, seed, walls=np.stack([_bernoulli_walls(seed + e, W, H) for e in range(E)]))
+    elif walls_kind == "perlin":
+        env.generate(cm.make_gen(0.15, 7, 3, 8, walls="perlin", perlin_scale=9.0, rng="reference"), seed)
+    else:
+        env.generate(cm.make_gen(0.0, 7, 3, 8, rng="reference"), seed)
+    rd = lambda w: env.read_state(w).cpu().numpy()  # noqa: E731
+    np.testing.assert_array_equal(rd(cm.S_ANTHILL_XYR), host["anthill_xyr"])
+    np.testing.assert_array_equal(rd(cm.S_WALLS), host["walls"])
+    np.testing.assert_array_equal(rd(cm.S_FOOD), host["food"])
+    np.testing.assert_array_equal(rd(cm.S_SEED), host["seed"].astype(np.float32))
+    np.testing.assert_array_equal(rd(cm.S_ROCK_CENTERS), host["rocks"][..., :2])
+    np.testing.assert_array_equal(rd(cm.S_ROCK_RW), host["rocks"][..., 2:])
+    xyt = rd(cm.S_ANTS_XYT)
+    np.testing.assert_array_equal(xyt[..., 2], host["ants_xyt"][..., 2])
+    np.testing.assert_allclose(xyt[..., :2], host["ants_xyt"][..., :2], rtol=0, atol=1e-11)
+    # and it steps: one observation + step from the generated state
+    obs, ast, rew = env.observe()
+    assert torch.isfinite(obs).all()
+
+
+def test_generate_with_the_reference_streams_draws_the_golden_initial_states():
+    """Directly against the reference: the initial ants, per-ant seeds and anthill the 13 golden fixtures recorded
+    (reference EnvironmentGenerator with the fixture's seed) come out of the device generator."""
+    from helpers import fixture_names, load_fixture
+    from antsrl_amd import config as cm
+    from antsrl_amd.batched import BatchedAntsEnv
+    for name in fixture_names():
+        cfg, init, F, meta = load_fixture(name)
+        if meta["n_rocks"]:
+            continue  # the fixtures' rocks were built by hand (the reference's rock branch raises NameError)
+        env = BatchedAntsEnv(cfg)
+        env.generate(cm.make_gen(0.0, 6, 3, 6, rng="reference"), int(meta["seed"]))
+        np.testing.assert_array_equal(env.read_state(cm.S_ANTHILL_XYR).cpu().numpy()[0], F["init_anthill_xyr"], err_msg=name)
+        np.testing.assert_array_equal(env.read_state(cm.S_SEED).cpu().numpy()[0], F["init_seed"].astype(np.float32), err_msg=name)
+        xyt = env.read_state(cm.S_ANTS_XYT).cpu().numpy()[0]
+        np.testing.assert_array_equal(xyt[:, 2], F["init_ants_xyt"][:, 2], err_msg=name)
+        np.testing.assert_allclose(xyt[:, :2], F["init_ants_xyt"][:, :2], rtol=0, atol=1e-11, err_msg=name)
