@@ -342,6 +342,137 @@ k_sweep_march(const KP p, const float *__restrict__ in, float *__restrict__ out,
 #undef MARCH_LOAD
 }
 
+
+// Radius 1, two channels, even H — the reference's own diffusion mode (DIFFUSE_FACTOR > 0, pheromone.py:5-10:
+// a 3x3 filter).  Same register march as k_sweep_march, with TWO columns per lane: every access is 16 bytes
+// (cells y, y+1 x channels 0, 1), a wave covers exactly 128 output columns (H = 256: two strips, every lane
+// busy; the one-column form needs 5 strips of 62 + 2 halo lanes), the y-neighbours of a lane's inner pair are
+// its own registers, the outer ones come from the adjacent lane by a whole-wave DPP shift, and the two halo
+// columns of the strip (127 cells apart) are one extra 8-byte load per row.
+//   out[x,y] = sum_{a,b} F[a,b] * in[x-a+1, y-b+1]      (convolve2d 'same', zero fill; taps split hi + lo)
+__global__ void __launch_bounds__(256)
+k_sweep_r1x2(const KP p, const float *__restrict__ in, float *__restrict__ out, const int seg_rows)
+{
+    constexpr int S = 3, NA = 5;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int e = blockIdx.y, W = p.W, H = p.H;
+    const int strip = blockIdx.x * 4 + wave;
+    __shared__ float taps[2 * 9];
+    if (threadIdx.x < 18) taps[threadIdx.x] = p.ftap[threadIdx.x]; // [b][a]{hi, lo}
+    __syncthreads();
+    if (strip * 128 >= H) return; // whole wave (no further barriers)
+    const int y = strip * 128 + 2 * lane;          // this lane's columns y, y + 1 (H even: both in or both out)
+    const bool col_in = y < H;
+    const int yc = col_in ? y : 0;
+    const float colmask = col_in ? 1.0f : 0.0f;
+    // halo columns of the strip: lanes 0..31 fetch column strip*128 - 1, lanes 32..63 column strip*128 + 128
+    const int yh = lane < 32 ? strip * 128 - 1 : strip * 128 + 128;
+    const bool halo_in = yh >= 0 && yh < H;
+    const int yhc = halo_in ? yh : 0;
+    const float halomask = halo_in ? 1.0f : 0.0f;
+    const size_t G = (size_t)W * H;
+    const float *src = in + (size_t)e * G * 2;
+    float *dst = out + (size_t)e * G * 2;
+    const uint32_t *walls = p.s.walls_bits + (size_t)e * p.words;
+    const bool clip = p.has_max_val && p.N > 0;
+    const float thr = (float)p.threshold, mx = (float)p.max_val;
+    float acc[NA][4]; // output row x = xi0 - 1 + j: {col0 ch0, col0 ch1, col1 ch0, col1 ch1}
+#pragma unroll
+    for (int j = 0; j < NA; ++j)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[j][c] = 0.0f;
+    const int x_lo = blockIdx.z * seg_rows, x_hi = min(x_lo + seg_rows, W);
+    float4 nv[S];
+    float2 nh[S];
+    uint32_t nword[S], nhword[S], ncell[S], nhcell[S];
+#define R1_LOAD(XI0)                                                                                 \
+    {                                                                                                \
+        _Pragma("unroll") for (int s = 0; s < S; ++s)                                                \
+        {                                                                                            \
+            const int xc = min(max((XI0) + s, 0), W - 1); /* clamped; masked to zero below */        \
+            ncell[s] = (uint32_t)(xc * H + yc);                                                      \
+            nhcell[s] = (uint32_t)(xc * H + yhc);                                                    \
+            nword[s] = walls[ncell[s] >> 5];                                                         \
+            nhword[s] = walls[nhcell[s] >> 5];                                                       \
+        }                                                                                            \
+        _Pragma("unroll") for (int s = 0; s < S; ++s)                                                \
+        {                                                                                            \
+            nv[s] = *reinterpret_cast<const float4 *>(src + (size_t)ncell[s] * 2);                   \
+            nh[s] = *reinterpret_cast<const float2 *>(src + (size_t)nhcell[s] * 2);                  \
+        }                                                                                            \
+    }
+    R1_LOAD(x_lo - 1)
+    for (int xi0 = x_lo - 1; xi0 < x_hi + 1; xi0 += S) {
+        float v[S][4], hv[S][2];
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            // zero fill outside the grid; walls.py:30 zeroes the INPUT of the convolution (arithmetic masks)
+            const float rowm = (xi0 + s >= 0 && xi0 + s < W) ? 1.0f : 0.0f;
+            const uint32_t sh0 = ncell[s] & 31u; // (even cell index: the pair's two bits sit in one word)
+            const float k0 = colmask * rowm * (float)(1u - ((nword[s] >> sh0) & 1u));
+            const float k1 = colmask * rowm * (float)(1u - ((nword[s] >> (sh0 + 1u)) & 1u));
+            const float kh = halomask * rowm * (float)(1u - ((nhword[s] >> (nhcell[s] & 31u)) & 1u));
+            v[s][0] = nv[s].x * k0; v[s][1] = nv[s].y * k0; v[s][2] = nv[s].z * k1; v[s][3] = nv[s].w * k1;
+            hv[s][0] = nh[s].x * kh; hv[s][1] = nh[s].y * kh;
+        }
+        R1_LOAD(xi0 + S) // prefetch (clamped addresses: a harmless re-read past the end)
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            // y-neighbours: in[x][y-1] of col0 = lane-1's col1 (lane 0: the left halo), in[x][y+2] of col1 = lane+1's
+            // col0 (lane 63: the right halo, fetched by lanes 32..63)
+            float lft[2], rgt[2];
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const float l = wave_shr1(v[s][2 + c]), r = wave_shl1(v[s][c]);
+                const float hl = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hv[s][c]), 0));
+                const float hr = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hv[s][c]), 63));
+                lft[c] = lane == 0 ? hl : l;
+                rgt[c] = lane == 63 ? hr : r;
+            }
+            // tap column b multiplies in[x][y - b + 1]: b = 0 -> right neighbour, 1 -> centre, 2 -> left neighbour
+#pragma unroll
+            for (int a = 0; a < S; ++a) {
+                const float f0h = taps[2 * (0 * S + a)], f0l = taps[2 * (0 * S + a) + 1];
+                const float f1h = taps[2 * (1 * S + a)], f1l = taps[2 * (1 * S + a) + 1];
+                const float f2h = taps[2 * (2 * S + a)], f2l = taps[2 * (2 * S + a) + 1];
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    float t0 = acc[s + a][c], t1 = acc[s + a][2 + c];
+                    // column y:     right = own col1, centre = own col0, left = lft
+                    t0 = fmaf(f0h, v[s][2 + c], t0); t0 = fmaf(f0l, v[s][2 + c], t0);
+                    t0 = fmaf(f1h, v[s][c], t0);     t0 = fmaf(f1l, v[s][c], t0);
+                    t0 = fmaf(f2h, lft[c], t0);      t0 = fmaf(f2l, lft[c], t0);
+                    // column y + 1: right = rgt, centre = own col1, left = own col0
+                    t1 = fmaf(f0h, rgt[c], t1);      t1 = fmaf(f0l, rgt[c], t1);
+                    t1 = fmaf(f1h, v[s][2 + c], t1); t1 = fmaf(f1l, v[s][2 + c], t1);
+                    t1 = fmaf(f2h, v[s][c], t1);     t1 = fmaf(f2l, v[s][c], t1);
+                    acc[s + a][c] = t0; acc[s + a][2 + c] = t1;
+                }
+            }
+        }
+        // rows j = 0..S-1 are complete
+#pragma unroll
+        for (int j = 0; j < S; ++j) {
+            const int x = xi0 - 1 + j;
+            if (x >= x_lo && x < x_hi && col_in) {
+                float r[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    float f = acc[j][c] < thr ? 0.0f : acc[j][c]; // pheromone.py:45
+                    if (clip) f = fminf(f, mx);
+                    r[c] = f;
+                }
+                store_stream(reinterpret_cast<float4 *>(dst + ((size_t)x * H + y) * 2), make_float4(r[0], r[1], r[2], r[3]));
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NA; ++j)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[j][c] = (j + S < NA) ? acc[j + S][c] : 0.0f;
+    }
+#undef R1_LOAD
+}
+
 // host-side launchers (called from antsrl_capi.hip)
 template <int C>
 static hipError_t launch_sweep_c(const KP &p, int cur, hipStream_t st)
@@ -368,6 +499,17 @@ static hipError_t launch_sweep_c(const KP &p, int cur, hipStream_t st)
         while ((long long)p.E * strips * nseg < 16 * 1024 && p.W / (nseg * 2) >= 64) nseg *= 2;
         const int seg_rows = (p.W + nseg - 1) / nseg;
         dim3 grid((strips + 3) / 4, p.E, (p.W + seg_rows - 1) / seg_rows);
+        if constexpr (C == 2) {
+            // radius 1 (the reference's 3x3 diffusion), even H: two columns per lane, 16-byte accesses
+            if (fr == 1 && (p.H & 1) == 0 && !PROF_ENV("ANTSRL_SWEEP_ONE_COLUMN")) {
+                const int strips2 = (p.H + 127) / 128;
+                int nseg2 = 1;
+                while ((long long)p.E * strips2 * nseg2 < 16 * 1024 && p.W / (nseg2 * 2) >= 64) nseg2 *= 2;
+                const int seg2 = (p.W + nseg2 - 1) / nseg2;
+                hipLaunchKernelGGL(k_sweep_r1x2, dim3((strips2 + 3) / 4, p.E, (p.W + seg2 - 1) / seg2), dim3(256), 0, st, p, in, out, seg2);
+                return hipGetLastError();
+            }
+        }
         if (p.filter_sep) {
             if (fr == 1) hipLaunchKernelGGL((k_sweep_march<C, 1, true>), grid, dim3(256), 0, st, p, in, out, seg_rows);
             else if (fr == 2) hipLaunchKernelGGL((k_sweep_march<C, 2, true>), grid, dim3(256), 0, st, p, in, out, seg_rows);
