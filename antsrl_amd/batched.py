@@ -27,6 +27,8 @@ _STATE_DTYPES = {
     cfgmod.S_ROCK_CENTERS: torch.float64, cfgmod.S_TIMESTEP: torch.int32, cfgmod.S_REWARD_STATE: torch.uint8,
     cfgmod.S_WALLS: torch.uint8, cfgmod.S_ANTHILL_AREA: torch.uint8, cfgmod.S_SEED: torch.float32,
     cfgmod.S_ANTHILL_XYR: torch.int32, cfgmod.S_ROCK_RW: torch.float64,
+    cfgmod.S_PHERO_C0: torch.float32, cfgmod.S_PHERO_C1: torch.float32, cfgmod.S_PHERO_C2: torch.float32,
+    cfgmod.S_PHERO_C3: torch.float32,
 }
 
 
@@ -164,15 +166,35 @@ class BatchedAntsEnv:
                 self._act_event.synchronize()  # the previous upload has left the staging buffer
             assert rotation.size == n and phero.size == n, "expected %d actions per array" % n
             h = self._host_act.numpy()
-            h[0] = rotation.reshape(c.n_envs, c.n_ants)
-            h[1] = phero.reshape(c.n_envs, c.n_ants)
+            h[0] = self._integral(rotation, "rotation").reshape(c.n_envs, c.n_ants)
+            h[1] = self._integral(phero, "pheromone").reshape(c.n_envs, c.n_ants)
             with torch.cuda.device(self.device):
                 self._dev_act.copy_(self._host_act, non_blocking=True)
                 self._act_event.record()
             return self._dev_act[0], self._dev_act[1]
-        rot = self._dev(rotation, torch.int8, (c.n_envs, c.n_ants))
-        ph = self._dev(phero, torch.int8, (c.n_envs, c.n_ants))
+        rot = self._dev(self._integral(rotation, "rotation"), torch.int8, (c.n_envs, c.n_ants))
+        ph = self._dev(self._integral(phero, "pheromone"), torch.int8, (c.n_envs, c.n_ants))
         return rot, ph
+
+    @staticmethod
+    def _integral(a, what):
+        """Actions are small integers (rotation in {-1, 0, 1} times max_rot_speed, RL_api.py:191; pheromone index in
+        {0, 1, 2}, ants.py:90-96) and travel as int8: a fractional value is refused, never truncated."""
+        if a is None:
+            return None
+        if torch.is_tensor(a):
+            if a.is_floating_point():
+                raise TypeError("%s actions must be an integer tensor (got %s): fractional rotations are not "
+                                "supported and would be truncated" % (what, a.dtype))
+            return a
+        arr = np.asarray(a)
+        if arr.dtype.kind == "f":
+            if not np.array_equal(arr, np.rint(arr)):
+                raise ValueError("%s actions must be whole numbers (the kernels take them as int8)" % what)
+            arr = arr.astype(np.int64)
+        if arr.size and (arr.min() < -128 or arr.max() > 127):
+            raise ValueError("%s actions out of the int8 range" % what)
+        return arr
 
     def outputs_to_host(self, want_obs: bool = True):
         """(obs, agent_state, reward, done) of the last step as fresh numpy arrays: ONE device-to-host copy
@@ -270,7 +292,11 @@ class BatchedAntsEnv:
             cfgmod.S_ROCK_CENTERS: (E, R, 2), cfgmod.S_TIMESTEP: (E,), cfgmod.S_REWARD_STATE: (E, N),
             cfgmod.S_WALLS: (E, W, H), cfgmod.S_ANTHILL_AREA: (E, W, H), cfgmod.S_SEED: (E, N),
             cfgmod.S_ANTHILL_XYR: (E, 3), cfgmod.S_ROCK_RW: (E, R, 2),
+            cfgmod.S_PHERO_C0: (E, W, H), cfgmod.S_PHERO_C1: (E, W, H), cfgmod.S_PHERO_C2: (E, W, H),
+            cfgmod.S_PHERO_C3: (E, W, H),
         }
+        if cfgmod.S_PHERO_C0 <= which <= cfgmod.S_PHERO_C3 and which - cfgmod.S_PHERO_C0 >= Cn:
+            raise _lib.AntsrlError("pheromone channel %d of %d" % (which - cfgmod.S_PHERO_C0, Cn))
         out = torch.empty(shapes[which], dtype=_STATE_DTYPES[which], device=self.device)
         if out.numel():
             with torch.cuda.device(self.device):

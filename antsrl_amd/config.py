@@ -30,11 +30,11 @@ CH_ANTS, CH_PHERO, CH_ANTHILL, CH_WALLS, CH_FOOD, CH_ROCKS = range(6)
 REWARD_NONE, REWARD_EXPLORATION, REWARD_FOOD, REWARD_ALL = range(4)
 PHERO_AUTO, PHERO_EXPLICIT_SWEEP = 0, 1
 TIMING_EVENTS = 5  # antsrl_set_timing_events
-Q_CELL_META, Q_SCALED_UNITS, Q_INTERLEAVED, Q_FILTER_SEPARABLE, Q_PERCEIVE_RUN = range(5)  # antsrl_query
+Q_CELL_META, Q_SCALED_UNITS, Q_INTERLEAVED, Q_FILTER_SEPARABLE, Q_PERCEIVE_RUN, Q_TIMESTEP = range(6)  # antsrl_query
 
 (S_ANTS_XYT, S_PREV_XY, S_HOLDING, S_MANDIBLES, S_ACTIVATION, S_PHERO, S_FOOD, S_EXPLORED,
  S_ANTHILL_FOOD, S_ROCK_CENTERS, S_TIMESTEP, S_REWARD_STATE, S_WALLS, S_ANTHILL_AREA,
- S_SEED, S_ANTHILL_XYR, S_ROCK_RW) = range(17)
+ S_SEED, S_ANTHILL_XYR, S_ROCK_RW, S_PHERO_C0, S_PHERO_C1, S_PHERO_C2, S_PHERO_C3) = range(21)
 
 
 class AntsCfg(C.Structure):

@@ -563,6 +563,7 @@ extern "C" int antsrl_query(const AntsHandle *h, int what, long long *value)
     case ANTSRL_Q_INTERLEAVED: *value = h->p.ps == 4 && h->p.fs == 4; break;
     case ANTSRL_Q_FILTER_SEPARABLE: *value = h->p.filter_sep; break;
     case ANTSRL_Q_PERCEIVE_RUN: *value = h->p.meta ? antsrl_perceive_run(h->p) : 0; break;
+    case ANTSRL_Q_TIMESTEP: *value = h->host_timestep; break;
     default: return fail(ANTSRL_E_INVALID, "bad query selector %d", what);
     }
     return ANTSRL_OK;
@@ -635,6 +636,8 @@ static size_t state_bytes(const AntsHandle *h, int which)
     case ANTSRL_S_TIMESTEP: return 4 * E;
     case ANTSRL_S_ANTHILL_XYR: return 4 * E * 3;
     case ANTSRL_S_ROCK_RW: return 8 * E * R * 2;
+    case ANTSRL_S_PHERO_C0: case ANTSRL_S_PHERO_C1: case ANTSRL_S_PHERO_C2: case ANTSRL_S_PHERO_C3:
+        return (size_t)(which - ANTSRL_S_PHERO_C0) < C ? 4 * E * G : 0;
     default: return 0;
     }
 }

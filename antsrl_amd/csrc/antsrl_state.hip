@@ -438,6 +438,17 @@ __global__ void k_read_state(const KP p, const int which, const int cur, void *_
             ((float *)dstv)[i] = v;
         }
         break;
+    case ANTSRL_S_PHERO_C0: case ANTSRL_S_PHERO_C1: case ANTSRL_S_PHERO_C2: case ANTSRL_S_PHERO_C3: {
+        const int c = which - ANTSRL_S_PHERO_C0; // one channel [E][W][H]
+        for (size_t i = t0; i < EG; i += stride) {
+            float v = p.s.phero[cur][i * p.ps + c];
+            if (p.scaled) {
+                v *= (float)p.g_now;
+                if (v < (float)p.threshold) v = 0.0f;
+            }
+            ((float *)dstv)[i] = v;
+        }
+    } break;
     case ANTSRL_S_FOOD: for (size_t i = t0; i < EG; i += stride) ((float *)dstv)[i] = p.s.food[i * p.fs]; break;
     case ANTSRL_S_EXPLORED:
     case ANTSRL_S_WALLS:

@@ -75,6 +75,14 @@ class RewardGather:
     # The step kernels can write reward / done straight into the gather's send buffer: two byte buffers
     # [E_local*N*4 reward | E_local done] used alternately (the gather of step t reads slot t % 2 while
     # step t + 1 writes the other one), so no staging copy is enqueued at all.
+    # EXPERIMENTAL until it has run on RCCL with more than one rank (the driver's 8-GPU node): its ordering rests
+    # on ProcessGroupNCCL's stream semantics — the collective waits for everything enqueued on the CURRENT stream
+    # when it is called, and Work.wait() makes the current stream wait for the collective.  The step kernels must
+    # therefore be enqueued on the stream that is current at outputs() / start_slot() time: recorded and checked.
+    @staticmethod
+    def _current_stream(device):
+        return torch.cuda.current_stream(device).cuda_stream if torch.device(device).type == "cuda" else None
+
     def outputs(self, slot: int):
         """(reward float32 [E_local, N], done uint8 [E_local]) views of send slot `slot` (0 or 1): bind them
         as the env's output tensors for the step whose results start_slot(slot) will gather."""
@@ -90,6 +98,7 @@ class RewardGather:
         z = self._zc
         if z["work"][slot] is not None:
             z["work"][slot].wait()  # the gather that last read this slot is ordered before the kernels that rewrite it
+        z.setdefault("stream", [None, None])[slot] = self._current_stream(self._send.device)
         sb = z["send"][slot]
         rew = sb[: self.max_local * self.N * 4].view(torch.float32).view(self.max_local, self.N)[: z["n_loc"]]
         done = sb[self.max_local * self.N * 4:][: z["n_loc"]]
@@ -100,6 +109,9 @@ class RewardGather:
         z = self._zc
         if z["work"][slot] is not None:
             z["work"][slot].wait()
+        if z.get("stream") and z["stream"][slot] != self._current_stream(self._send.device):
+            raise RuntimeError("RewardGather.start_slot: the current stream changed since outputs(%d): the step kernels "
+                               "and the gather would not be ordered" % slot)
         z["work"][slot] = dist.all_gather_into_tensor(z["recv"][slot], z["send"][slot], group=self.group, async_op=True)
 
     def finish_slot(self, slot: int):
@@ -121,3 +133,53 @@ class RewardGather:
         """Blocking form: -> (reward [E_total, N], done [E_total]) on every rank."""
         self.start(reward_local, done_local)
         return self.finish()
+
+
+class ShardedStepper:
+    """The per-step sequence of a sharded run — what `bench.py --gpus N` executes on every rank, factored out so
+    that the CPU (gloo, world size 2) test drives the very same code with a stand-in for the device step.
+
+        stepper = ShardedStepper(env, gather, mode)          # env: anything with .reward / .done tensors
+        for t in range(K): stepper.step(t, lambda: env.step_update(...))
+        reward_all, done_all = stepper.drain()               # last step's gathered batch (None without a gather)
+
+    mode "staged" (default): the step writes the env's own reward / done tensors, start() snapshots them into the
+    send buffer (two small device copies) and launches the all-gather asynchronously under the next step.
+    mode "zero_copy": the env's reward / done are re-pointed at the gather's alternating send slots, so the kernels
+    write the collective's payload in place (experimental, see RewardGather.outputs)."""
+
+    def __init__(self, env, gather: Optional[RewardGather], mode: str = "staged"):
+        if mode not in ("staged", "zero_copy"):
+            raise ValueError("mode must be 'staged' or 'zero_copy'")
+        self.env, self.gather, self.mode = env, gather, mode
+        self._last_slot = None
+
+    def step(self, t: int, do_step) -> None:
+        g = self.gather
+        if g is not None and self.mode == "zero_copy":
+            self.env.reward, self.env.done = g.outputs(t % 2)
+        do_step()
+        if g is None:
+            return
+        # the path's only exchange: the reward / done all-gather (SURVEY.md §8(e)), one fused collective per
+        # step, left running under the next step's kernels
+        if self.mode == "zero_copy":
+            g.start_slot(t % 2)
+            self._last_slot = t % 2
+        else:
+            g.start(self.env.reward, self.env.done)
+
+    def drain(self):
+        """Waits for every gather still in flight; -> the most recent (reward_all, done_all) or None."""
+        g = self.gather
+        if g is None:
+            return None
+        if self.mode == "zero_copy":
+            last = self._last_slot
+            out = None
+            for s in (0, 1):
+                r = g.finish_slot(s)
+                if s == last:
+                    out = r
+            return out
+        return g.finish()

@@ -294,13 +294,7 @@ class _DeviceAnthill(Anthill):
 
     @property
     def _xyr_now(self):
-        # area bitmap -> bounding box gives back centre and radius of the rasterised disc
-        a = self._read(cm.S_ANTHILL_AREA).astype(bool)
-        out = np.zeros((a.shape[0], 3), np.int64)
-        for e in range(a.shape[0]):
-            xs, ys = np.nonzero(a[e])
-            out[e] = ((xs.min() + xs.max()) // 2, (ys.min() + ys.max()) // 2, (xs.max() - xs.min()) // 2)
-        return out
+        return self._read(cm.S_ANTHILL_XYR).astype(np.int64)  # [E, 3]: x, y, radius as the device generator drew them
 
     x = property(lambda self: int(self._xyr_now[0, 0]) if self._xyr_now.shape[0] == 1 else self._xyr_now[:, 0])
     y = property(lambda self: int(self._xyr_now[0, 1]) if self._xyr_now.shape[0] == 1 else self._xyr_now[:, 1])

@@ -65,8 +65,10 @@ class Environment:  # environment/environment.py:21-47
     def timestep(self):
         if self._backend is None:
             return 1
-        ts = self._backend.read_state(cm.S_TIMESTEP).cpu().numpy()
-        return int(ts[0]) if ts.size == 1 else ts
+        # every env of a batch steps in lockstep: the library mirrors the counter on the host (no device round trip)
+        ts = self._backend.query(cm.Q_TIMESTEP)
+        n = self._backend.cfg.n_envs
+        return ts if n == 1 else np.full((n,), ts, dtype=np.int32)
 
     def update(self, wall_jitter=None):
         """Environment.update (environment.py:42-47): one antsrl_update call.  `wall_jitter`
@@ -112,7 +114,7 @@ class Pheromone(_View):  # environment/pheromone.py:20-45
 
     @property
     def phero(self):
-        p = self._read(cm.S_PHERO)[:, self.index]
+        p = self._read(cm.S_PHERO_C0 + self.index)  # this object's channel only
         return p[0] if p.shape[0] == 1 else p
 
     def visualize_copy(self, newenv):

@@ -181,6 +181,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--repeats", type=int, default=5, help="timed regions of --steps steps each; the median is reported")
+    ap.add_argument("--gather", default="staged", choices=["staged", "zero_copy"],
+                    help="N > 1: how reward/done reach the all-gather (zero_copy: the kernels write the send slots in place; "
+                         "experimental until it has run on RCCL with more than one rank)")
     ap.add_argument("--no-explicit-sweep", action="store_true",
                     help="skip the short extra run with the per-step sweep kernel forced (explicit_sweep record)")
     ap.add_argument("--policy", default=None, choices=["random", "mlp"],
@@ -254,19 +257,18 @@ def main():
         policy = LinearPolicy(cfg.pside * cfg.pside * cfg.n_channels, dev, seed=5 + rank)
         env.observe()  # main.py:88: first observation feeds the first action
 
-    def one_step(t):
-        if gather is not None:
-            env.reward, env.done = gather.outputs(t % 2)
+    from antsrl_amd.dist import ShardedStepper
+    stepper = ShardedStepper(env, gather, args.gather)  # the N > 1 sequence: tests/test_dist_cpu.py runs the same code
+
+    def device_step(t):
         if policy is not None:  # agent.get_action on the device, then api.step + env.update
             a_rot, a_ph = policy.act(env.obs, env.agent_state, env=env)
             env.step_update(a_rot, a_ph, None)
         else:
             env.step_update(rot[t % RING], ph[t % RING], None)
-        if gather is not None:
-            # the path's only exchange: the reward/done all-gather, one fused
-            # collective per step, left running under the next step's kernels.  The step wrote
-            # reward/done straight into the gather's send slot (no staging copy).
-            gather.start_slot(t % 2)
+
+    def one_step(t):
+        stepper.step(t, lambda: device_step(t))
 
     for t in range(args.warmup):
         one_step(t)
@@ -282,9 +284,7 @@ def main():
     evs = HipEvents(NEV * len(timed_steps)) if timing else None
 
     def barrier():
-        if gather is not None:
-            gather.finish_slot(0)  # the last steps' gathers belong to the timed region
-            gather.finish_slot(1)
+        stepper.drain()  # the last steps' gathers belong to the timed region
         torch.cuda.synchronize(dev)
         if dist is not None:
             dist.barrier()
@@ -380,7 +380,7 @@ def main():
                                    if meta_path else "k_act + ") + ("k_update_one" if cfg.n_ants <= 1024 else "k_update"),
                        "policy": ("linear DQN net (F+2 -> 32 -> 3+3) in-loop, bf16 MFMA" if policy is not None
                                   else "uniform random, pre-generated on device"),
-                       "parallelism": "env-sharded x%d, reward/done all-gather" % world},
+                       "parallelism": "env-sharded x%d, reward/done all-gather (%s)" % (world, args.gather)},
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -207,6 +207,10 @@ enum {
     ANTSRL_S_SEED = 14,        /* float   [E][N]                        */
     ANTSRL_S_ANTHILL_XYR = 15, /* int32   [E][3]      Anthill.x, .y, .radius (anthill.py:21-23) */
     ANTSRL_S_ROCK_RW = 16,     /* double  [E][R][2]   CircleObstacles.radiuses, .weights (circle_obstacles.py:19-20) */
+    ANTSRL_S_PHERO_C0 = 17,    /* float   [E][W][H]   one pheromone channel: Pheromone.phero of pheromone 0 ...   */
+    ANTSRL_S_PHERO_C1 = 18,    /*                     ... 1 (a view of ONE Pheromone object reads one channel,    */
+    ANTSRL_S_PHERO_C2 = 19,    /*                     not all of them)                                            */
+    ANTSRL_S_PHERO_C3 = 20,
     ANTSRL_S_COUNT_
 };
 
@@ -292,6 +296,8 @@ enum {
     ANTSRL_Q_INTERLEAVED = 2,      /* 1: {p0, p1, food, meta} 16-byte cell records                        */
     ANTSRL_Q_FILTER_SEPARABLE = 3, /* 1: DIFFUSE_FILTER detected as rank-1 (separable stencil march)      */
     ANTSRL_Q_PERCEIVE_RUN = 4,     /* ants per wave of k_perceive (0 without the cell-meta path)          */
+    ANTSRL_Q_TIMESTEP = 5,         /* Environment.timestep (environment.py:27,45) as the host mirrors it: every env of a
+                                      handle steps in lockstep, so no device read is needed                */
     ANTSRL_Q_COUNT_
 };
 int antsrl_query(const AntsHandle *h, int what, long long *value);

@@ -86,6 +86,64 @@ def test_sharded_envs_and_reward_gather(world, E):
             np.testing.assert_array_equal(zc[step][1], 1 - want_d)
 
 
+class _FakeEnv:
+    """Stand-in for BatchedAntsEnv on CPU: `step_update` writes this rank's reward / done into whatever tensors
+    env.reward / env.done currently point at — exactly what the kernels do with the pointers they are handed."""
+
+    def __init__(self, lo, hi, n):
+        self.lo, self.hi, self.n = lo, hi, n
+        self.reward = torch.zeros((hi - lo, n), dtype=torch.float32)
+        self.done = torch.zeros((hi - lo,), dtype=torch.uint8)
+
+    def step_update(self, t):
+        self.reward.copy_(torch.full((self.hi - self.lo, self.n), 100.0 + t) + torch.arange(self.lo, self.hi, dtype=torch.float32)[:, None])
+        self.done.copy_(torch.tensor([(e + t) % 2 for e in range(self.lo, self.hi)], dtype=torch.uint8))
+
+
+def _stepper_worker(rank, world, port, E, N, mode, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from antsrl_amd.dist import ShardedStepper
+        lo, hi = shard_range(E, rank, world)
+        env = _FakeEnv(lo, hi, N)
+        st = ShardedStepper(env, RewardGather(E, N, "cpu"), mode)
+        seen = []
+        for t in range(5):  # bench.py's loop: step, gather left in flight under the next step
+            st.step(t, lambda: env.step_update(t))
+        r, d = st.drain()
+        seen.append((r.clone().numpy(), d.clone().numpy()))
+        st.step(5, lambda: env.step_update(5))  # the loop keeps working after a drain (bench: one region after another)
+        r, d = st.drain()
+        seen.append((r.clone().numpy(), d.clone().numpy()))
+        q.put((rank, seen))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["staged", "zero_copy"])
+def test_bench_step_loop_two_ranks(mode):
+    """bench.py's N > 1 sequence (antsrl_amd.dist.ShardedStepper: env.reward / env.done re-pointed at the gather's
+    slots or snapshotted, one async all-gather per step, drain at the region's end) with two gloo ranks and a
+    stand-in step writer: every rank ends up with the whole batch of the LAST step."""
+    world, E, N = 2, 6, 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_stepper_worker, args=(r, world, port, E, N, mode, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for _, seen in res:
+        for (r, d), t in zip(seen, (4, 5)):
+            np.testing.assert_array_equal(r, np.full((E, N), 100.0 + t) + np.arange(E, dtype=np.float32)[:, None])
+            np.testing.assert_array_equal(d, np.array([(e + t) % 2 for e in range(E)], np.uint8))
+
+
 def test_shard_range_partitions():
     for E in (1, 7, 8, 1024, 8192):
         for world in (1, 2, 3, 8):

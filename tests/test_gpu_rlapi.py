@@ -173,3 +173,31 @@ def test_outputs_to_host_matches_device_tensors():
     b.step_update(rot[0], ph[0])
     a.step_update(rot[0], ph[0])
     np.testing.assert_array_equal(b.outputs_to_host()[2], a.reward.cpu().numpy())
+
+
+def test_host_views_read_only_what_they_show():
+    """Pheromone.phero reads ONE channel (ANTSRL_S_PHERO_C<i>), equal to that slice of the all-channel read-out;
+    Environment.timestep is the library's host mirror (no device round trip) and follows the device counter;
+    fractional actions are refused, not truncated."""
+    import torch
+    from antsrl_amd import config as cm
+    from antsrl_amd.batched import BatchedAntsEnv
+    from antsrl_amd.synth import random_actions, synth_init
+    cfg = cm.make_cfg(3, 20, 48, 40, deposit_strength=256.0)
+    env = BatchedAntsEnv(cfg)
+    env.reset(synth_init(cfg, seed=4, n_food_discs=4, food_rmin=2, food_rmax=5))
+    rot, ph = random_actions(cfg, 4, seed=8)
+    for t in range(4):
+        env.step_update(rot[t], ph[t], None)
+    allc = env.read_state(cm.S_PHERO)
+    assert float(allc.abs().sum()) > 0
+    for c in range(2):
+        assert torch.equal(env.read_state(cm.S_PHERO_C0 + c), allc[:, c])
+    with pytest.raises(Exception):
+        env.read_state(cm.S_PHERO_C2)
+    assert env.query(cm.Q_TIMESTEP) == 5 and (env.read_state(cm.S_TIMESTEP).cpu().numpy() == 5).all()
+    with pytest.raises(ValueError):
+        env.step(rot[0].astype(np.float64) * 0.5, ph[0])
+    with pytest.raises(TypeError):
+        env.step(torch.zeros((3, 20), device=env.device), torch.zeros((3, 20), dtype=torch.int8, device=env.device))
+    env.step(rot[0].astype(np.float64), ph[0])  # whole-number floats are fine (numpy promotes argmax - 1 to int64 anyway)
