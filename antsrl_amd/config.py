@@ -29,6 +29,7 @@ MAX_PHERO = 4
 CH_ANTS, CH_PHERO, CH_ANTHILL, CH_WALLS, CH_FOOD, CH_ROCKS = range(6)
 REWARD_NONE, REWARD_EXPLORATION, REWARD_FOOD, REWARD_ALL = range(4)
 PHERO_AUTO, PHERO_EXPLICIT_SWEEP = 0, 1
+ACT_AUTO, ACT_CELL_META, ACT_SINGLE_KERNEL = 0, 1, 2
 TIMING_EVENTS = 5  # antsrl_set_timing_events
 Q_CELL_META, Q_SCALED_UNITS, Q_INTERLEAVED, Q_FILTER_SEPARABLE, Q_PERCEIVE_RUN, Q_TIMESTEP = range(6)  # antsrl_query
 
@@ -76,6 +77,8 @@ class AntsCfg(C.Structure):
         ("fct_explore_holding", C.c_double),
         ("fct_headinganthill", C.c_double),
         ("rng_seed", C.c_uint64),
+        ("act_path", C.c_int32),
+        ("_pad1", C.c_int32),
     ]
 
     # convenience -----------------------------------------------------------
@@ -170,7 +173,7 @@ def make_cfg(n_envs: int, n_ants: int, w: int, h: int, *, n_phero: int = 2, n_ro
              reward_threshold: float = 1.0, fct_explore: float = 1.0, fct_food: float = 1.0,
              fct_anthill: float = 5.0, fct_explore_holding: float = 0.0,
              fct_headinganthill: float = 1.0, rng_seed: int = 0x5EED,
-             phero_mode: int = PHERO_AUTO) -> AntsCfg:
+             phero_mode: int = PHERO_AUTO, act_path: int = ACT_AUTO) -> AntsCfg:
     """Build an AntsCfg with the reference's defaults (see module docstring)."""
     c = AntsCfg()
     c.abi_version = ABI_VERSION
@@ -230,6 +233,7 @@ def make_cfg(n_envs: int, n_ants: int, w: int, h: int, *, n_phero: int = 2, n_ro
     c.fct_explore_holding, c.fct_headinganthill = fct_explore_holding, fct_headinganthill
     c.rng_seed = rng_seed
     c.phero_mode = phero_mode
+    c.act_path = act_path
     return c
 
 

@@ -78,6 +78,8 @@ extern "C" int antsrl_abi_version(void) { return ANTSRL_ABI_VERSION; }
 extern "C" size_t antsrl_cfg_size(void) { return sizeof(AntsCfg); }
 extern "C" const char *antsrl_last_error(void) { return g_err; }
 
+static void fill_kp(const AntsCfg *c, KP *p);
+
 static int validate(const AntsCfg *c)
 {
     if (!c) return fail(ANTSRL_E_INVALID, "cfg is NULL");
@@ -110,6 +112,15 @@ static int validate(const AntsCfg *c)
     if (c->reward_kind < ANTSRL_REWARD_NONE || c->reward_kind > ANTSRL_REWARD_ALL)
         return fail(ANTSRL_E_INVALID, "bad reward_kind");
     if (c->has_max_val && !(c->phero_max_val > 0)) return fail(ANTSRL_E_INVALID, "phero_max_val must be > 0");
+    if (c->act_path < ANTSRL_ACT_AUTO || c->act_path > ANTSRL_ACT_SINGLE_KERNEL) return fail(ANTSRL_E_INVALID, "bad act_path");
+    if (c->act_path == ANTSRL_ACT_CELL_META) {
+        KP kp;
+        fill_kp(c, &kp);
+        if (!kp.meta)
+            return fail(ANTSRL_E_UNSUPPORTED, "ANTSRL_ACT_CELL_META needs 2 pheromone channels, the generator's channel order "
+                                              "([Ants, Phero0, Phero1, Anthill, Walls, Food(, Rocks)]), a perception of 128..368 values "
+                                              "per ant over at most 64 cells, and at most 4096 ants per env");
+    }
     return ANTSRL_OK;
 }
 
@@ -130,8 +141,6 @@ static bool use_interleaved(const AntsCfg *c)
     static const bool off = PROF_ENV("ANTSRL_NO_INTERLEAVE") != nullptr;
     return !off && use_scaled(c) && c->n_phero == 2;
 }
-
-static void fill_kp(const AntsCfg *c, KP *p);
 
 // Carves the workspace; with base == NULL only computes the size.
 static size_t carve(const AntsCfg *c, DState *s, unsigned char *base)
@@ -256,9 +265,12 @@ static void fill_kp(const AntsCfg *c, KP *p)
     p->ps = use_interleaved(c) ? 4 : c->n_phero;
     p->fs = use_interleaved(c) ? 4 : 1;
     p->g_now = p->g_dep = p->inv_g_dep = 1.0;
-    // cell-meta path (k_move + k_perceive) for the reference's perception shapes; ANTSRL_LEGACY_ACT (profiling
-    // build only) keeps k_act for A/B runs
-    p->meta = (antsrl_meta_supported(*p) && !PROF_ENV("ANTSRL_LEGACY_ACT")) ? 1 : 0;
+    // cell-meta path (k_move + k_perceive) for the reference's perception shapes (AntsCfg.act_path pins either)
+    // Tiny batches (fewer than 8192 ants in all: BASELINE config 1's single 32-ant env) are launch-latency bound:
+    // one kernel fewer wins there (c1: 20.7 us/step with k_act against 25.8 with k_move + k_perceive), so they keep
+    // k_act whenever its LDS plan fits with the grid's bit maps in LDS.
+    const bool tiny = (long long)p->E * p->N < 8192 && antsrl_act_fits(*p) && !antsrl_act_needs_hbm_maps(*p);
+    p->meta = antsrl_meta_supported(*p) && (c->act_path == ANTSRL_ACT_CELL_META || (c->act_path == ANTSRL_ACT_AUTO && !tiny)) ? 1 : 0;
     if (p->meta && p->fs == 1) p->fs = 2;
 }
 

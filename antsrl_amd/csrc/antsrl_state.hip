@@ -485,25 +485,28 @@ __global__ void k_read_state(const KP p, const int which, const int cur, void *_
     }
 }
 
-// Measurement helper (antsrl_bench_copy): 16 bytes per lane, four independent loads in flight per lane,
-// streaming stores.
+// Measurement helper (antsrl_bench_copy): 16 bytes per lane.  Every 256-thread workgroup copies ONE contiguous
+// 16 KiB chunk (four independent 16-byte loads per lane in flight, then four stores) and workgroups take the
+// chunks in address order: the chip then reads and writes a compact, advancing window, which is what the memory
+// side rewards (profiles/fill_clone_probe.hip: 6.1-6.8 TB/s of writes with 4-16 KiB per workgroup against 4.9-5.3
+// with 64 KiB and more).
 __global__ void __launch_bounds__(256) k_copy16(uint4 *__restrict__ dst, const uint4 *__restrict__ src, const size_t n)
 {
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    for (; i + 3 * stride < n; i += 4 * stride) {
-        const uint4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
-        dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
-    }
-    for (; i < n; i += stride) dst[i] = src[i];
+    const size_t base = (size_t)blockIdx.x * 1024 + threadIdx.x;
+    uint4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = src[min(base + (size_t)u * 256, n - 1)];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+        if (base + (size_t)u * 256 < n) dst[base + (size_t)u * 256] = v[u];
 }
 
 hipError_t antsrl_launch_copy16(void *dst, const void *src, size_t bytes, hipStream_t st)
 {
     const size_t n = bytes / 16;
     if (n == 0) return hipSuccess;
-    size_t blocks = (n + 255) / 256;
-    if (blocks > 256 * 8) blocks = 256 * 8; // 8 workgroups of 256 threads per CU
+    const size_t blocks = (n + 1023) / 1024;
+    if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
     hipLaunchKernelGGL(k_copy16, dim3((unsigned)blocks), dim3(256), 0, st, (uint4 *)dst, (const uint4 *)src, n);
     return hipGetLastError();
 }

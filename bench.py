@@ -181,6 +181,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--repeats", type=int, default=5, help="timed regions of --steps steps each; the median is reported")
+    ap.add_argument("--act-path", default="auto", choices=["auto", "meta", "kact"],
+                    help="AntsCfg.act_path: auto (the library's measured choice), meta (k_move + k_perceive), kact (round 1's "
+                         "single kernel) — for A/B runs on one box")
     ap.add_argument("--gather", default="staged", choices=["staged", "zero_copy"],
                     help="N > 1: how reward/done reach the all-gather (zero_copy: the kernels write the send slots in place; "
                          "experimental until it has run on RCCL with more than one rank)")
@@ -227,6 +230,7 @@ def main():
         W_["R"] = args.rocks
     E = args.envs or W_["E"]
     extra = dict(n_rocks=W_["R"], deposit_strength=256.0, max_time=1 << 30,
+                 act_path={"auto": cm.ACT_AUTO, "meta": cm.ACT_CELL_META, "kact": cm.ACT_SINGLE_KERNEL}[args.act_path],
                  phero_mode=cm.PHERO_EXPLICIT_SWEEP if args.explicit_sweep else cm.PHERO_AUTO)
     if W_["radius3"]:
         ax = np.arange(-3, 4)
@@ -280,8 +284,10 @@ def main():
     # per-kernel HIP events on every 4th step only: the event records between two kernels cost
     # ~15 us of stream idle time (rocprof trace), which would otherwise tax `value` by ~4 %
     EV_EVERY = 4
-    timed_steps = list(range(0, K, EV_EVERY))
+    timed_steps = [(rep, t) for rep in range(REPEATS) for t in range(0, K, EV_EVERY)]  # in EVERY region: the kernel
+    # averages then cover the same launches as the step time (and as a rocprofv3 --stats of the same command)
     evs = HipEvents(NEV * len(timed_steps)) if timing else None
+    ev_slot = {rt: i for i, rt in enumerate(timed_steps)}
 
     def barrier():
         stepper.drain()  # the last steps' gathers belong to the timed region
@@ -292,16 +298,15 @@ def main():
 
     # REPEATS timed regions of exactly K steps each, every one bracketed by barrier + synchronize on both
     # sides and reduced with MAX over the ranks; `value` is the MEDIAN region (median of 5),
-    # the spread is reported beside it.  Kernel events are recorded during the last region only.
+    # the spread is reported beside it.
     region_s = []
     step_no = args.warmup
     for rep in range(REPEATS):
-        last = rep == REPEATS - 1
         barrier()
         t0 = time.perf_counter()
         for t in range(K):
-            if timing and last and t % EV_EVERY == 0:
-                env.set_timing_events([evs.ev[NEV * (t // EV_EVERY) + i].value for i in range(NEV)])
+            if timing and t % EV_EVERY == 0:
+                env.set_timing_events([evs.ev[NEV * ev_slot[(rep, t)] + i].value for i in range(NEV)])
             one_step(step_no)
             step_no += 1
         barrier()

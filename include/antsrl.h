@@ -72,6 +72,12 @@ enum {
  * radius always use the LDS-tiled sweep. */
 enum { ANTSRL_PHERO_AUTO = 0, ANTSRL_PHERO_EXPLICIT_SWEEP = 1 };
 
+/* Which kernels run RLApi.step / RLApi.observation.  AUTO picks by measurement: the cell-meta path (k_move +
+ * k_perceive) wherever it is supported, except for batches of fewer than 8192 ants in all, which are launch-latency
+ * bound and keep the single kernel.  The other two values pin a path (antsrl_create refuses a configuration the
+ * pinned path does not support): results are identical, both are parity-tested. */
+enum { ANTSRL_ACT_AUTO = 0, ANTSRL_ACT_CELL_META = 1, ANTSRL_ACT_SINGLE_KERNEL = 2 };
+
 /* reward kinds (environment/rewards/) */
 enum {
     ANTSRL_REWARD_NONE = 0,        /* Reward base: zeros, reward.py:19,38       */
@@ -131,6 +137,9 @@ typedef struct AntsCfg {
     /* Walls.update jitter (walls.py:28) when no explicit draws are supplied:
      * counter-based generator keyed on (rng_seed, env, timestep, ant). */
     uint64_t rng_seed;
+
+    int32_t act_path; /* ANTSRL_ACT_* (no reference counterpart) */
+    int32_t _pad1;
 } AntsCfg;
 
 /* Initial state of every environment = what EnvironmentGenerator.generate

@@ -1,17 +1,15 @@
 #!/bin/bash
-# The round's profile set, one gpurun call:  bash profiles/final_passes.sh
-# kernel trace + stats of the default bench, then PMC passes (each in its own run, --kernel-trace only).
-set -e
+# The round's profile set (one gpurun call per configuration keeps each call short):
+#   CONFIGS="c3" bash profiles/final_passes.sh
+# kernel trace + stats of the default-length bench, then PMC passes (each in its own run, --kernel-trace only).
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
-cd /tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_final -- \
-    python3 $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline > $R/gpurun_out/bench_under_rocprof.json 2> $R/gpurun_out/prof_final.err
-bash $R/profiles/pmc_pass.sh f_fetch FETCH_SIZE
-bash $R/profiles/pmc_pass.sh f_write WRITE_SIZE
-bash $R/profiles/pmc_pass.sh f_sq SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU SQ_ACTIVE_INST_ANY
-bash $R/profiles/pmc_pass.sh f_tcc TCC_HIT_sum TCC_MISS_sum   # (more TCC counters in one pass exceed the hardware's counter slots: rocprofv3 aborts)
-BENCH_ARGS=--explicit-sweep bash $R/profiles/pmc_pass.sh x_fetch FETCH_SIZE
-BENCH_ARGS=--explicit-sweep bash $R/profiles/pmc_pass.sh x_write WRITE_SIZE
-cd $R && python3 bench.py > gpurun_out/bench_final.json 2> gpurun_out/bench_final.err
-tail -c 1500 gpurun_out/bench_final.json
+for c in ${CONFIGS:-c3}; do
+  cd /tmp
+  rm -rf $R/gpurun_out/prof_$c
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$c -- \
+      python3 $R/bench.py --config $c --steps 100 --repeats 2 --no-cpu-baseline --no-explicit-sweep > $R/gpurun_out/bench_${c}_rocprof.json 2> $R/gpurun_out/prof_$c.err
+  tail -c 600 $R/gpurun_out/bench_${c}_rocprof.json; echo
+  BENCH_ARGS="--config $c --warmup 400" bash $R/profiles/pmc_pass.sh ${c}_fetch FETCH_SIZE | grep "k_perceive\|k_move\|k_update\|k_act\|k_sweep\|k_policy"
+  BENCH_ARGS="--config $c --warmup 400" bash $R/profiles/pmc_pass.sh ${c}_write WRITE_SIZE | grep "k_perceive\|k_move\|k_update\|k_act\|k_sweep\|k_policy"
+done

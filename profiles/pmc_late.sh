@@ -4,6 +4,6 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 export BENCH_ARGS="--warmup 400"
 bash $R/profiles/pmc_pass.sh l_fetch FETCH_SIZE | grep "k_perceive\|k_move\|k_update\|k_act"
 bash $R/profiles/pmc_pass.sh l_write WRITE_SIZE | grep "k_perceive\|k_move\|k_update\|k_act"
-export ANTSRL_LIB=$R/antsrl_amd/lib/libantsrl_hip_prof.so ANTSRL_LEGACY_ACT=1
+export BENCH_ARGS="--warmup 400 --act-path kact"
 bash $R/profiles/pmc_pass.sh ll_fetch FETCH_SIZE | grep "k_perceive\|k_move\|k_update\|k_act"
 bash $R/profiles/pmc_pass.sh ll_write WRITE_SIZE | grep "k_perceive\|k_move\|k_update\|k_act"

@@ -13,4 +13,4 @@ P=$R/antsrl_amd/lib/libantsrl_hip_prof.so
 for run in ${RUNS:-8 16 32 64}; do one "run=$run" $P ANTSRL_PRC_RUN=$run; done
 one "product" $R/antsrl_amd/lib/libantsrl_hip.so A=1
 for v in ${VARIANTS:-nostore nomark nostore_nomark}; do one "$v" $V/$v.so A=1; done
-one "legacy k_act" $P ANTSRL_LEGACY_ACT=1
+BENCH_ARGS="$BENCH_ARGS --act-path kact" one "legacy k_act" $P A=1

@@ -11,4 +11,4 @@ one "prof" $P A=1
 for pad in 10 20 40 60; do one "lds_pad=$pad" $P ANTSRL_PRC_LDS_PAD=$pad; done
 for v in merge_masked flush3 flush3_merge; do one "$v" $V/$v.so A=1; done
 one "prof again" $P A=1
-one "legacy k_act" $P ANTSRL_LEGACY_ACT=1
+BENCH_ARGS="$BENCH_ARGS --act-path kact" one "legacy k_act" $P A=1

@@ -11,4 +11,4 @@ P=$R/antsrl_amd/lib/libantsrl_hip_prof.so
 one "product" $R/antsrl_amd/lib/libantsrl_hip.so A=1
 for v in ${VARIANTS}; do one "$v" $V/$v.so A=1; done
 one "product again" $R/antsrl_amd/lib/libantsrl_hip.so A=1
-one "legacy k_act" $P ANTSRL_LEGACY_ACT=1
+BENCH_ARGS="$BENCH_ARGS --act-path kact" one "legacy k_act" $P A=1

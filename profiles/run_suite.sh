@@ -1,6 +1,6 @@
 #!/bin/bash
 # One gpurun call: the GPU parity suite, then the default bench with the product library and, for an A/B on
-# the same box, the round-1 k_act path (profiling library, ANTSRL_LEGACY_ACT=1).
+# the same box, the round-1 k_act path (bench.py --act-path kact = AntsCfg.act_path ANTSRL_ACT_SINGLE_KERNEL).
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
 timeout -k 10 900 python -m pytest tests -x -q -m gpu > gpurun_out/gpu_tests.log 2>&1; rc=$?
@@ -8,7 +8,7 @@ tail -15 gpurun_out/gpu_tests.log
 [ $rc -ne 0 ] && exit $rc
 for i in 1 2; do
   timeout -k 10 300 python bench.py --no-cpu-baseline --no-explicit-sweep > gpurun_out/bench_new_$i.json 2> gpurun_out/bench_new_$i.err || { tail -5 gpurun_out/bench_new_$i.err; exit 1; }
-  ANTSRL_LIB=$R/antsrl_amd/lib/libantsrl_hip_prof.so ANTSRL_LEGACY_ACT=1 timeout -k 10 300 python bench.py --no-cpu-baseline --no-explicit-sweep > gpurun_out/bench_legacy_$i.json 2> gpurun_out/bench_legacy_$i.err || { tail -5 gpurun_out/bench_legacy_$i.err; exit 1; }
+  timeout -k 10 300 python bench.py --act-path kact --no-cpu-baseline --no-explicit-sweep > gpurun_out/bench_legacy_$i.json 2> gpurun_out/bench_legacy_$i.err || { tail -5 gpurun_out/bench_legacy_$i.err; exit 1; }
 done
 python - <<'PY'
 import json

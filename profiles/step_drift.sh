@@ -3,7 +3,7 @@
 # explored cells)?  40 consecutive regions of 50 steps each, product path and round-1 k_act.
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
-for lib in libantsrl_hip.so libantsrl_hip_prof.so; do
-  env ANTSRL_LIB=$R/antsrl_amd/lib/$lib ANTSRL_LEGACY_ACT=1 python bench.py --no-cpu-baseline --no-explicit-sweep --warmup 0 --steps 50 --repeats 40 ${BENCH_ARGS} 2>/dev/null | python3 -c "
-import sys, json; d=json.loads(sys.stdin.read()); print('$lib', d['config']['kernels']); print(' '.join('%.3f' % x for x in d['ms_per_step_regions'])); print(d['roofline']['kernel_ms'])"
+for act in meta kact; do
+  python bench.py --act-path $act --no-cpu-baseline --no-explicit-sweep --warmup 0 --steps 50 --repeats 40 ${BENCH_ARGS} 2>/dev/null | python3 -c "
+import sys, json; d=json.loads(sys.stdin.read()); print('$act', d['config']['kernels']); print(' '.join('%.3f' % x for x in d['ms_per_step_regions'])); print(d['roofline']['kernel_ms'])"
 done

@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Condenses the rocprofv3 output of profiles/final_passes.sh (under gpurun_out/) into the tracked files:
+
+    python profiles/summarize_r02.py r02
+
+  profiles/<round>/kernel_stats_<config>.csv   rocprofv3 --kernel-trace --stats, the step's kernels
+  profiles/<round>/pmc_summary.md / .json       mean of the last 15 launches per kernel and counter
+  profiles/traffic_<config>.json                HBM bytes per launch per kernel (read by bench.py)
+HBM bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: FETCH_SIZE / WRITE_SIZE are in KiB, and on gfx950
+FETCH_SIZE tallies each 128-byte fabric read as 64 bytes (MI355X_MICROARCH.md, HBM section; confirmed in round 1
+on k_sweep0: 520 MiB read, 260 MiB reported)."""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+rnd = sys.argv[1]
+out = os.path.join(ROOT, "profiles", rnd)
+os.makedirs(out, exist_ok=True)
+summary = {}
+for cfg in ("c3", "c2", "c4", "c5"):
+    st = sorted(glob.glob(os.path.join(ROOT, "gpurun_out", "prof_%s" % cfg, "*", "*_kernel_stats.csv")), key=os.path.getmtime)
+    if st:
+        rows = list(csv.reader(open(st[-1])))
+        keep = [rows[0]] + [r for r in rows[1:] if r[0].lstrip("void ").startswith("k_")]
+        csv.writer(open(os.path.join(out, "kernel_stats_%s.csv" % cfg), "w")).writerows(keep)
+    per = {}
+    for cname in ("fetch", "write"):
+        fs = sorted(glob.glob(os.path.join(ROOT, "gpurun_out", "pmc_%s_%s" % (cfg, cname), "*", "*_counter_collection.csv")), key=os.path.getmtime)
+        if not fs:
+            continue
+        agg = collections.defaultdict(list)
+        for r in csv.DictReader(open(fs[-1])):
+            k = r["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0]
+            if k.startswith("k_") and not k.startswith(("k_reset", "k_gen", "k_collect", "k_copy", "k_read", "k_policy_w")):
+                agg[(k, r["Counter_Name"])].append(float(r["Counter_Value"]))
+        for (k, c), v in agg.items():
+            t = v[-15:]
+            per.setdefault(k, {})[c] = sum(t) / len(t)
+    if per:
+        summary[cfg] = per
+        traffic = {k: int((2 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024) for k, d in per.items() if "FETCH_SIZE" in d and "WRITE_SIZE" in d}
+        traffic["_source"] = "profiles/%s/pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, %s; late steps of the episode: warm-up 400)" % (rnd, cfg)
+        json.dump(traffic, open(os.path.join(ROOT, "profiles", "traffic_%s.json" % cfg), "w"), indent=1, sort_keys=True)
+json.dump(summary, open(os.path.join(out, "pmc_summary.json"), "w"), indent=1, sort_keys=True)
+with open(os.path.join(out, "pmc_summary.md"), "w") as f:
+    f.write("# %s PMC summary (rocprofv3 --pmc, one pass per counter, bench.py --warmup 400 --steps 20)\n\n" % rnd)
+    f.write("| config | kernel | FETCH_SIZE KiB (x2 = bytes read) | WRITE_SIZE KiB | HBM MB per launch |\n|---|---|---|---|---|\n")
+    for cfg in sorted(summary):
+        for k in sorted(summary[cfg]):
+            d = summary[cfg][k]
+            if "FETCH_SIZE" in d and "WRITE_SIZE" in d:
+                f.write("| %s | %s | %.0f | %.0f | %.1f |\n" % (cfg, k, d["FETCH_SIZE"], d["WRITE_SIZE"], (2 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024 / 1e6))
+print(json.dumps({c: {k: round((2 * d.get("FETCH_SIZE", 0) + d.get("WRITE_SIZE", 0)) * 1024 / 1e6, 1) for k, d in v.items()} for c, v in summary.items()}))

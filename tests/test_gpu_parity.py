@@ -86,18 +86,28 @@ def _modes():
     return [cm.PHERO_AUTO, cm.PHERO_EXPLICIT_SWEEP]
 
 
+@pytest.mark.parametrize("act", [1, 2], ids=["cell_meta", "single_kernel"])
 @pytest.mark.parametrize("mode", [0, 1], ids=["auto", "explicit_sweep"])
 @pytest.mark.parametrize("name", fixture_names())
-def test_hip_matches_reference_golden(torch_mod, name, mode):
+def test_hip_matches_reference_golden(torch_mod, name, mode, act):
     """Replay every recorded reference run through antsrl_step / antsrl_update / antsrl_observe,
-    with the scaled pheromone units (auto) and with the explicit per-step sweep."""
+    with the scaled pheromone units (auto) and with the explicit per-step sweep, on BOTH kernel paths
+    (AntsCfg.act_path: k_move + k_perceive on the cell-meta layout, and the single k_act)."""
+    from antsrl_amd import _lib
     from antsrl_amd.batched import BatchedAntsEnv
     n_envs = 3
     cfg, init, F, meta = load_fixture(name, n_envs)
     if mode == 1 and cfg.filter_radius != 0:
         pytest.skip("filters with a radius always use the tiled sweep")
     cfg.phero_mode = mode
-    env = BatchedAntsEnv(cfg)
+    cfg.act_path = act
+    try:
+        env = BatchedAntsEnv(cfg)
+    except _lib.AntsrlError as e:
+        if act == 1 and "ANTSRL_ACT_CELL_META" in str(e):
+            pytest.skip("a perception shape the cell-meta path does not take")
+        raise
+    assert env.query(0) == (1 if act == 1 else 0)
     env.reset(init)
     from antsrl_amd import config as cm
     np.testing.assert_array_equal(_cpu(env.read_state(cm.S_ANTHILL_AREA))[1], F["init_anthill_area"].astype(np.uint8))
