@@ -172,12 +172,13 @@ __device__ __forceinline__ float wave_shl1(float v)
 // 4 S FMAs per input value instead of 2 S^2.
 template <int C, int R, bool SEP>
 __global__ void __launch_bounds__(256)
-k_sweep_march(const KP p, const float *__restrict__ in, float *__restrict__ out, const int seg_rows)
+k_sweep_march(const KP p, const float *__restrict__ in, float *__restrict__ out, const int seg_rows, const int nstrips, const int nsegs)
 {
     constexpr int S = 2 * R + 1, OUTW = 64 - 2 * R, NA = 2 * S - 1;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int e = blockIdx.y, W = p.W, H = p.H;
-    const int strip = blockIdx.x * 4 + wave;
+    // one wave per (column strip, row segment) pair, an environment's pairs packed densely into its workgroups
+    const int unit = blockIdx.x * 4 + wave, strip = unit % nstrips, segi = unit / nstrips;
     // The S*S taps {hi, lo} sit in LDS and are read back (uniform address = broadcast) right where
     // they are used: ~100 wave-uniform scalars do not fit the SGPR file — as kernel arguments the
     // compiler hoists them out of the march and spills them through v_writelane/v_readlane.
@@ -188,7 +189,7 @@ k_sweep_march(const KP p, const float *__restrict__ in, float *__restrict__ out,
         taps[2 * S + threadIdx.x] = p.fsep_v[threadIdx.x];
     }
     __syncthreads();
-    if (strip * OUTW >= H) return; // whole wave (no further barriers)
+    if (segi >= nsegs) return; // whole wave (no further barriers)
     const int y = strip * OUTW - R + lane;
     const bool col_in = y >= 0 && y < H;
     const bool col_out = lane >= R && lane < 64 - R && y < H;
@@ -209,7 +210,7 @@ k_sweep_march(const KP p, const float *__restrict__ in, float *__restrict__ out,
 
     // This wave produces output rows [x_lo, x_hi): it marches input rows x_lo - R .. x_hi - 1 + R
     // (rows outside the grid count as zero), i.e. 2R rows of overlap with its x-neighbour segment.
-    const int x_lo = blockIdx.z * seg_rows, x_hi = min(x_lo + seg_rows, W);
+    const int x_lo = segi * seg_rows, x_hi = min(x_lo + seg_rows, W);
     // one block of S rows is always in flight ahead of the block being accumulated
     float nv[S][C];
     uint32_t nword[S], ncell[S];
@@ -351,16 +352,17 @@ k_sweep_march(const KP p, const float *__restrict__ in, float *__restrict__ out,
 // columns of the strip (127 cells apart) are one extra 8-byte load per row.
 //   out[x,y] = sum_{a,b} F[a,b] * in[x-a+1, y-b+1]      (convolve2d 'same', zero fill; taps split hi + lo)
 __global__ void __launch_bounds__(256)
-k_sweep_r1x2(const KP p, const float *__restrict__ in, float *__restrict__ out, const int seg_rows)
+k_sweep_r1x2(const KP p, const float *__restrict__ in, float *__restrict__ out, const int seg_rows, const int nstrips, const int nsegs)
 {
     constexpr int S = 3, NA = 5;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int e = blockIdx.y, W = p.W, H = p.H;
-    const int strip = blockIdx.x * 4 + wave;
+    // one wave per (column strip, row segment) pair, an environment's pairs packed densely into its workgroups
+    const int unit = blockIdx.x * 4 + wave, strip = unit % nstrips, segi = unit / nstrips;
     __shared__ float taps[2 * 9];
     if (threadIdx.x < 18) taps[threadIdx.x] = p.ftap[threadIdx.x]; // [b][a]{hi, lo}
     __syncthreads();
-    if (strip * 128 >= H) return; // whole wave (no further barriers)
+    if (segi >= nsegs) return; // whole wave (no further barriers)
     const int y = strip * 128 + 2 * lane;          // this lane's columns y, y + 1 (H even: both in or both out)
     const bool col_in = y < H;
     const int yc = col_in ? y : 0;
@@ -381,7 +383,7 @@ k_sweep_r1x2(const KP p, const float *__restrict__ in, float *__restrict__ out, 
     for (int j = 0; j < NA; ++j)
 #pragma unroll
         for (int c = 0; c < 4; ++c) acc[j][c] = 0.0f;
-    const int x_lo = blockIdx.z * seg_rows, x_hi = min(x_lo + seg_rows, W);
+    const int x_lo = segi * seg_rows, x_hi = min(x_lo + seg_rows, W);
     float4 nv[S];
     float2 nh[S];
     uint32_t nword[S], nhword[S], ncell[S], nhcell[S];
@@ -473,6 +475,137 @@ k_sweep_r1x2(const KP p, const float *__restrict__ in, float *__restrict__ out, 
 #undef R1_LOAD
 }
 
+// Radius 2..3, two channels, even H, RANK-1 filter (c4's Gaussian): the separable march with TWO columns per lane
+// (16-byte accesses).  Strips overlap by HL = ceil(R / 2) lanes on either side (the halo), so a wave covers 128 columns
+// and produces 128 - 4 HL of them (R = 3: 120; the one-column form: 58 of 64).  Each input row is convolved across the
+// lanes with v (neighbour columns: the lane's other column, and the adjacent lanes' columns by whole-wave DPP shifts of
+// one and two lanes), the result feeds the S running output rows with u; nothing is kept per block but the accumulators
+// and the prefetched rows.  out[x,y] = sum_a u[a] sum_b v[b] in[x-a+R, y-b+R]   (taps split hi + lo)
+template <int R>
+__global__ void __launch_bounds__(256)
+k_sweep_sep2(const KP p, const float *__restrict__ in, float *__restrict__ out, const int seg_rows, const int nstrips, const int nsegs)
+{
+    constexpr int S = 2 * R + 1, HL = (R + 1) / 2, OUTW = 128 - 4 * HL;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // one wave per (column strip, row segment) pair, the pairs of an environment packed densely into its workgroups:
+    // no wave is launched only to exit (strips per row rarely divide by 4), so the CUs keep their full wave count
+    const int e = blockIdx.y, W = p.W, H = p.H;
+    const int unit = blockIdx.x * 4 + wave, strip = unit % nstrips, segi = unit / nstrips;
+    __shared__ float taps[4 * S]; // u {hi, lo} [S], then v {hi, lo} [S]
+    if (threadIdx.x < 2 * S) {
+        taps[threadIdx.x] = p.fsep_u[threadIdx.x];
+        taps[2 * S + threadIdx.x] = p.fsep_v[threadIdx.x];
+    }
+    __syncthreads();
+    if (segi >= nsegs) return; // whole wave (no further barriers)
+    const int y = strip * OUTW - 2 * HL + 2 * lane; // this lane's columns y, y + 1 (even: both inside the grid or both outside)
+    const bool col_in = y >= 0 && y < H;
+    const bool col_out = lane >= HL && lane < 64 - HL && y < H;
+    const int yc = col_in ? y : 0;
+    const float colmask = col_in ? 1.0f : 0.0f;
+    const size_t G = (size_t)W * H;
+    const float *src = in + (size_t)e * G * 2;
+    float *dst = out + (size_t)e * G * 2;
+    const uint32_t *walls = p.s.walls_bits + (size_t)e * p.words;
+    const bool clip = p.has_max_val && p.N > 0;
+    const float thr = (float)p.threshold, mx = (float)p.max_val;
+    // the filter taps as wave-uniform scalars (SGPRs), hi and lo parts
+    float uh[S], ul[S], vh[S], vl[S];
+#pragma unroll
+    for (int a = 0; a < S; ++a) {
+        uh[a] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, taps[2 * a])));
+        ul[a] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, taps[2 * a + 1])));
+        vh[a] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, taps[2 * S + 2 * a])));
+        vl[a] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, taps[2 * S + 2 * a + 1])));
+    }
+    // a ring of S running output rows: input row xin feeds rows xin - R .. xin + R, row xin - R is complete after it.
+    // The loop advances S input rows per turn, so the ring slot of every (input row, tap) pair is static.
+    // All arithmetic on {channel 0, channel 1} PAIRS: v_pk_fma_f32 does both channels' FMA in one instruction (each
+    // half is the IEEE fma of the scalar form), which halves the VALU work that otherwise co-limits this kernel.
+    typedef float v2f __attribute__((ext_vector_type(2)));
+#define FMA2(t, q, r) __builtin_elementwise_fma((v2f)(t), (q), (r))
+#define SHR2(q) (v2f){wave_shr1((q).x), wave_shr1((q).y)}
+#define SHL2(q) (v2f){wave_shl1((q).x), wave_shl1((q).y)}
+    v2f acc[S][2]; // [ring slot][column y, column y + 1]
+#pragma unroll
+    for (int j = 0; j < S; ++j) acc[j][0] = acc[j][1] = (v2f)(0.0f);
+    const int x_lo = segi * seg_rows, x_hi = min(x_lo + seg_rows, W);
+    float4 nv[S];
+    uint32_t nword[S], ncell[S];
+#define SEP2_LOAD1(XI0, s)                                                                           \
+    {                                                                                                \
+        const int xc = min(max((XI0) + (s), 0), W - 1); /* clamped; masked to zero when used */      \
+        ncell[s] = (uint32_t)(xc * H + yc);                                                          \
+        nword[s] = walls[ncell[s] >> 5];                                                             \
+        nv[s] = *reinterpret_cast<const float4 *>(src + (size_t)ncell[s] * 2);                       \
+    }
+#pragma unroll
+    for (int s = 0; s < S; ++s) SEP2_LOAD1(x_lo - R, s)
+    for (int xi0 = x_lo - R; xi0 < x_hi + R; xi0 += S) {
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            // zero fill outside the grid; walls.py:30 zeroes the INPUT of the convolution (arithmetic masks)
+            const float rowm = (xi0 + s >= 0 && xi0 + s < W) ? 1.0f : 0.0f;
+            const uint32_t sh0 = ncell[s] & 31u; // (even cell index: the pair's two bits sit in one word)
+            const float k0 = colmask * rowm * (float)(1u - ((nword[s] >> sh0) & 1u));
+            const float k1 = colmask * rowm * (float)(1u - ((nword[s] >> (sh0 + 1u)) & 1u));
+            const v2f a0 = (v2f){nv[s].x, nv[s].y} * (v2f)(k0), a1 = (v2f){nv[s].z, nv[s].w} * (v2f)(k1); // columns y, y + 1
+            SEP2_LOAD1(xi0 + S, s) // the same row of the next turn (clamped addresses: a harmless re-read past the end)
+            const v2f m1_0 = SHR2(a0), m1_1 = SHR2(a1); // lane - 1: columns y - 2, y - 1
+            const v2f p1_0 = SHL2(a0), p1_1 = SHL2(a1); // lane + 1: columns y + 2, y + 3
+            // nb0[d + R] = in[y + d], nb1[d + R] = in[y + 1 + d] for d = -R..R
+            v2f nb0[S], nb1[S];
+            nb0[R] = a0; nb1[R] = a1;
+            nb0[R + 1] = a1; nb1[R - 1] = a0;
+            nb0[R - 1] = m1_1; nb1[R + 1] = p1_0;
+            nb0[R - 2] = m1_0; nb0[R + 2] = p1_0;
+            nb1[R - 2] = m1_1; nb1[R + 2] = p1_1;
+            if constexpr (R == 3) {
+                const v2f m2_1 = SHR2(m1_1); // lane - 2: column y - 3
+                const v2f p2_0 = SHL2(p1_0); // lane + 2: column y + 4
+                nb0[R - 3] = m2_1; nb0[R + 3] = p1_1;
+                nb1[R - 3] = m1_0; nb1[R + 3] = p2_0;
+            }
+            // input row xi0 + s convolved across the columns with v: tap column b multiplies in[. - b + R]; summed
+            // centre first, then outwards (the one-column march's order)
+            v2f h0 = FMA2(vh[R], nb0[R], (v2f)(0.0f)), h1 = FMA2(vh[R], nb1[R], (v2f)(0.0f));
+            h0 = FMA2(vl[R], nb0[R], h0); h1 = FMA2(vl[R], nb1[R], h1);
+#pragma unroll
+            for (int d = 1; d <= R; ++d) {
+                h0 = FMA2(vh[R + d], nb0[R - d], h0); h1 = FMA2(vh[R + d], nb1[R - d], h1);
+                h0 = FMA2(vl[R + d], nb0[R - d], h0); h1 = FMA2(vl[R + d], nb1[R - d], h1);
+                h0 = FMA2(vh[R - d], nb0[R + d], h0); h1 = FMA2(vh[R - d], nb1[R + d], h1);
+                h0 = FMA2(vl[R - d], nb0[R + d], h0); h1 = FMA2(vl[R - d], nb1[R + d], h1);
+            }
+            // out[xin + a - R] += u[a] h: ring slot (s + a - R) mod S
+#pragma unroll
+            for (int a = 0; a < S; ++a) {
+                const int slot = (s + a - R + 2 * S) % S;
+                acc[slot][0] = FMA2(uh[a], h0, acc[slot][0]); acc[slot][1] = FMA2(uh[a], h1, acc[slot][1]);
+                acc[slot][0] = FMA2(ul[a], h0, acc[slot][0]); acc[slot][1] = FMA2(ul[a], h1, acc[slot][1]);
+            }
+            { // output row xin - R just received its last contribution (tap row 0)
+                const int slot = (s - R + 2 * S) % S;
+                const int x = xi0 + s - R;
+                if (x >= x_lo && x < x_hi && col_out) {
+                    float r[4] = {acc[slot][0].x, acc[slot][0].y, acc[slot][1].x, acc[slot][1].y};
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        r[c] = r[c] < thr ? 0.0f : r[c]; // pheromone.py:45
+                        if (clip) r[c] = fminf(r[c], mx);
+                    }
+                    store_stream(reinterpret_cast<float4 *>(dst + ((size_t)x * H + y) * 2), make_float4(r[0], r[1], r[2], r[3]));
+                }
+                acc[slot][0] = acc[slot][1] = (v2f)(0.0f);
+            }
+        }
+    }
+#undef FMA2
+#undef SHR2
+#undef SHL2
+#undef SEP2_LOAD1
+}
+
 // host-side launchers (called from antsrl_capi.hip)
 template <int C>
 static hipError_t launch_sweep_c(const KP &p, int cur, hipStream_t st)
@@ -492,31 +625,44 @@ static hipError_t launch_sweep_c(const KP &p, int cur, hipStream_t st)
         }
     } else if (!PROF_ENV("ANTSRL_SWEEP_TILED")) {
         const int fr = p.filter_radius;
-        const int strips = (p.H + (64 - 2 * fr) - 1) / (64 - 2 * fr);
-        // split the march along x into segments of >= 64 rows until the chip has ~16 waves per SIMD
-        // to choose from (each extra segment re-reads 2R rows)
-        int nseg = 1;
-        while ((long long)p.E * strips * nseg < 16 * 1024 && p.W / (nseg * 2) >= 64) nseg *= 2;
-        const int seg_rows = (p.W + nseg - 1) / nseg;
-        dim3 grid((strips + 3) / 4, p.E, (p.W + seg_rows - 1) / seg_rows);
+        // The march is split along x into segments (each re-reads 2R rows, mostly from L2 / the Infinity Cache) and one
+        // wave takes one (column strip, segment) pair; the pairs of an environment fill its workgroups densely.
+        // Rows per segment, measured (profiles/r02/sweep_seg_explore.txt): radius 1 — 16 (c3 + 3x3 diffusion, two columns
+        // per lane: 0.191 ms against 0.205 at 32, 0.219 at 64); radius 3, two columns — 32 (c4: 0.827 ms against 0.854 at
+        // 64, 0.900 at 16, 0.907 at 128); radius 3, one column — 64 (0.936 against 1.001 at 32, 1.035 at 128).  Enough
+        // waves to keep every SIMD full to the end, short enough streams to keep the chip's write window compact.
+        const bool two_col = C == 2 && (p.H & 1) == 0 && !PROF_ENV("ANTSRL_SWEEP_ONE_COLUMN");
+        int seg_rows = std::min(p.W, fr == 1 ? 16 : (two_col && p.filter_sep) || fr == 2 ? 32 : 64);
+        if (const char *v = PROF_ENV("ANTSRL_SWEEP_SEG")) seg_rows = std::max(1, std::min(p.W, atoi(v)));
+        const int nsegs = (p.W + seg_rows - 1) / seg_rows;
         if constexpr (C == 2) {
             // radius 1 (the reference's 3x3 diffusion), even H: two columns per lane, 16-byte accesses
-            if (fr == 1 && (p.H & 1) == 0 && !PROF_ENV("ANTSRL_SWEEP_ONE_COLUMN")) {
+            if (fr == 1 && two_col) {
                 const int strips2 = (p.H + 127) / 128;
-                int nseg2 = 1;
-                while ((long long)p.E * strips2 * nseg2 < 16 * 1024 && p.W / (nseg2 * 2) >= 64) nseg2 *= 2;
-                const int seg2 = (p.W + nseg2 - 1) / nseg2;
-                hipLaunchKernelGGL(k_sweep_r1x2, dim3((strips2 + 3) / 4, p.E, (p.W + seg2 - 1) / seg2), dim3(256), 0, st, p, in, out, seg2);
+                hipLaunchKernelGGL(k_sweep_r1x2, dim3((strips2 * nsegs + 3) / 4, p.E), dim3(256), 0, st, p, in, out, seg_rows, strips2, nsegs);
+                return hipGetLastError();
+            }
+            // radius 2..3 with a rank-1 filter (c4's Gaussian), even H: the separable march, two columns per lane
+            if (fr >= 2 && p.filter_sep && two_col) {
+                const int outw = 128 - 4 * ((fr + 1) / 2);
+                const int strips2 = (p.H + outw - 1) / outw;
+                const dim3 grid2((strips2 * nsegs + 3) / 4, p.E);
+                if (fr == 2) hipLaunchKernelGGL(k_sweep_sep2<2>, grid2, dim3(256), 0, st, p, in, out, seg_rows, strips2, nsegs);
+                else hipLaunchKernelGGL(k_sweep_sep2<3>, grid2, dim3(256), 0, st, p, in, out, seg_rows, strips2, nsegs);
                 return hipGetLastError();
             }
         }
+        const int strips = (p.H + (64 - 2 * fr) - 1) / (64 - 2 * fr);
+        const dim3 grid((strips * nsegs + 3) / 4, p.E);
+#define MARCH_GO(RR, SEPV) hipLaunchKernelGGL((k_sweep_march<C, RR, SEPV>), grid, dim3(256), 0, st, p, in, out, seg_rows, strips, nsegs)
         if (p.filter_sep) {
-            if (fr == 1) hipLaunchKernelGGL((k_sweep_march<C, 1, true>), grid, dim3(256), 0, st, p, in, out, seg_rows);
-            else if (fr == 2) hipLaunchKernelGGL((k_sweep_march<C, 2, true>), grid, dim3(256), 0, st, p, in, out, seg_rows);
-            else hipLaunchKernelGGL((k_sweep_march<C, 3, true>), grid, dim3(256), 0, st, p, in, out, seg_rows);
-        } else if (fr == 1) hipLaunchKernelGGL((k_sweep_march<C, 1, false>), grid, dim3(256), 0, st, p, in, out, seg_rows);
-        else if (fr == 2) hipLaunchKernelGGL((k_sweep_march<C, 2, false>), grid, dim3(256), 0, st, p, in, out, seg_rows);
-        else hipLaunchKernelGGL((k_sweep_march<C, 3, false>), grid, dim3(256), 0, st, p, in, out, seg_rows);
+            if (fr == 1) MARCH_GO(1, true);
+            else if (fr == 2) MARCH_GO(2, true);
+            else MARCH_GO(3, true);
+        } else if (fr == 1) MARCH_GO(1, false);
+        else if (fr == 2) MARCH_GO(2, false);
+        else MARCH_GO(3, false);
+#undef MARCH_GO
     } else { // LDS-tiled float64 reference variant (A/B and cross-check: ANTSRL_SWEEP_TILED=1)
         const int fr = p.filter_radius;
         const size_t lds = (size_t)(SW_TX + 2 * fr) * (SW_TY + 2 * fr) * C * sizeof(float);

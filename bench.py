@@ -339,7 +339,9 @@ def main():
                 kern.pop("sweep")  # scaled pheromone units: no sweep kernel is launched at all
             dom = max(kern, key=kern.get)
             sweep_name = ("k_sweep0" if cfg.filter_radius == 0 else
-                          "k_sweep_r1x2" if cfg.filter_radius == 1 and cfg.n_phero == 2 and cfg.h % 2 == 0 else "k_sweep_march")
+                          "k_sweep_r1x2" if cfg.filter_radius == 1 and cfg.n_phero == 2 and cfg.h % 2 == 0 else
+                          "k_sweep_sep2" if cfg.n_phero == 2 and cfg.h % 2 == 0 and env.query(cm.Q_FILTER_SEPARABLE) else
+                          "k_sweep_march")
             names = dict(sweep=sweep_name, act="k_act", move="k_move",
                          perceive="k_perceive", update="k_update_one" if cfg.n_ants <= 1024 else "k_update")
             achieved = ab[dom] * E / (kern[dom] * 1e-3) / 1e9

@@ -1,0 +1,13 @@
+#!/bin/bash
+R=${GRAFT_REPO_ROOT:-/root/repo}
+cd $R
+P=$R/antsrl_amd/lib/libantsrl_hip_prof.so
+run() { cfg=$1; shift; env ANTSRL_LIB=$P "$@" python bench.py $cfg --no-cpu-baseline --no-explicit-sweep --repeats 1 --steps 30 --warmup 5 2>/dev/null | python3 -c "
+import sys, json; d=json.loads(sys.stdin.read()); k=d['roofline']['kernel_ms']; sw=[(n,v) for n,v in k.items() if 'sweep' in n][0]; print('%-22s %-52s %s %.4f ms  step %.4f' % ('$cfg', '$*', sw[0], sw[1], d['ms_per_step']))"; }
+for seg in 8 12 16 24; do run "--diffuse 0.02" ANTSRL_SWEEP_SEG=$seg; done
+run "--config c4" A=1
+run "--config c4" ANTSRL_SWEEP_ONE_COLUMN=1
+run "--diffuse 0.02" A=1
+run "--diffuse 0.02" ANTSRL_SWEEP_ONE_COLUMN=1
+run "--config c2 --diffuse 0.02" A=1
+run "--config c2 --diffuse 0.02" ANTSRL_SWEEP_SEG=64
