@@ -355,6 +355,34 @@ def test_config4_shape_radius3_vs_oracle(torch_mod):
     _compare_with_oracle(torch_mod, cfg, synth_init(cfg, seed=11), steps=6, seed=8, jitter_mode="builtin")
 
 
+def _stencil_filter(radius, separable, seed):
+    rng = np.random.default_rng(seed)
+    if separable:
+        f = np.outer(0.2 + rng.random(2 * radius + 1), 0.2 + rng.random(2 * radius + 1))  # asymmetric rank-1
+    else:
+        f = 0.1 + rng.random((2 * radius + 1, 2 * radius + 1))
+    return f / f.sum() * 0.97
+
+
+@pytest.mark.parametrize("radius,separable", [(1, False), (1, True), (2, True), (2, False), (3, True), (3, False)])
+@pytest.mark.parametrize("W,H", [
+    (40, 40),      # one strip, one segment, most lanes outside the grid
+    (33, 64),      # odd W: a ragged last row segment
+    (70, 122),     # H just past one two-column strip of radius 3 (120 outputs) and just under radius 1's (128)
+    (37, 250),     # several strips, the last one ragged
+    (100, 41),     # odd H: the one-column march
+    (131, 256),    # W not a multiple of any segment length
+])
+def test_stencil_shapes_vs_oracle(torch_mod, radius, separable, W, H):
+    """Every marching stencil kernel (one column / two columns per lane, general / rank-1 filter) on grid shapes
+    that exercise the strip and segment edges: walls zero the stencil's input (walls.py:30), zero fill outside the
+    grid (pheromone.py:44), the 0.01 cut (:45).  Asymmetric filters, so a transposed or mirrored tap shows."""
+    from antsrl_amd.config import make_cfg
+    from antsrl_amd.synth import synth_init
+    cfg = make_cfg(2, 96, W, H, filt=_stencil_filter(radius, separable, 10 * radius + separable), deposit_strength=256.0)
+    _compare_with_oracle(torch_mod, cfg, synth_init(cfg, seed=W + H), steps=5, seed=radius, jitter_mode="builtin")
+
+
 def test_scaled_units_edge_cases(torch_mod):
     """Scaled pheromone units against the oracle where they need care: an initial grid with
     pheromone on wall cells, ants that START on wall cells (their deposits live for exactly one
