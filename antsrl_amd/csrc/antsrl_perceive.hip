@@ -196,7 +196,9 @@ __host__ __device__ __forceinline__ PrcOff prc_offsets(int run, int PP, int K, i
     return o;
 }
 
-#define PRC_TPB 256
+#ifndef PRC_TPB
+#define PRC_TPB 256 // 4 waves per workgroup; 64 / 128 measured no better (profiles/r02/prc_tpb.txt)
+#endif
 
 // HAS_OBS is a template parameter on purpose: with the observation stores behind a run-time branch the
 // compiler cannot count them, every wait on a gather becomes vmcnt(0), i.e. a wait for the previous
