@@ -5,7 +5,7 @@ counts, forward shifts.  Each case is a few steps of step + update with injected
 import numpy as np
 import pytest
 
-from test_gpu_parity import _compare_with_oracle, _cpu, check_obs, torch_mod  # noqa: F401  (the parity suite's checks and fixture)
+from test_gpu_parity import _anthill_dist, _check_reward, _compare_with_oracle, _cpu, check_obs, torch_mod  # noqa: F401  (the parity suite's checks and fixture)
 
 pytestmark = pytest.mark.gpu
 
@@ -70,6 +70,7 @@ def test_random_configuration_vs_oracle(torch_mod, seed):
     act = rng.choice([0.0, 10.0], size=(E, N, cfg.n_phero)).astype(np.float32)
     env.set_activation(act)
     orc.set_activation(act)
+    prev_dist = _anthill_dist(init, orc.ants_xyt)
     for t in range(5):
         rot = rng.integers(-1, 2, (E, N), dtype=np.int8)
         jit = rng.random((E, N))
@@ -77,7 +78,8 @@ def test_random_configuration_vs_oracle(torch_mod, seed):
         o_obs, o_ast, o_rew, o_done = orc.step(rot, None)
         for e in range(E):
             check_obs(cfg, _cpu(obs)[e], o_obs[e], "seed %d step %d env %d" % (seed, t, e))
-        np.testing.assert_array_equal(_cpu(rew), o_rew.astype(np.float32))
+        _check_reward(cfg, init, _cpu(rew), o_rew, orc.ants_xyt, prev_dist, "seed %d step %d" % (seed, t))
+        prev_dist = _anthill_dist(init, orc.ants_xyt)
         np.testing.assert_array_equal(_cpu(done), o_done)
         env.update(jit)
         orc.update(jit)
@@ -110,26 +112,32 @@ def test_random_configuration_fused_calls_and_standalone_observation(torch_mod, 
         for e in range(E):
             check_obs(cfg, g[e], want[e], "seed %d %s env %d" % (seed, ctx, e))
 
+    prev_dist = [_anthill_dist(init, orc.ants_xyt)]
+
+    def same_reward(got, want, ctx):  # (bit-exact but for heading-term ties, see _check_reward)
+        _check_reward(cfg, init, _cpu(got), want, orc.ants_xyt, prev_dist[0], "seed %d %s" % (seed, ctx))
+        prev_dist[0] = _anthill_dist(init, orc.ants_xyt)
+
     obs, ast, rew = env.observe()
     o_obs, o_ast, o_rew = orc.observe()
     same_obs(obs, o_obs, "first observation")
-    np.testing.assert_array_equal(_cpu(rew), o_rew.astype(np.float32))
+    same_reward(rew, o_rew, "first observation")
     for t in range(6):
         rot = rng.integers(-1, 2, (E, N), dtype=np.int8)
         ph = rng.integers(0, 3, (E, N), dtype=np.int8) if t != 3 else None
         jit = rng.random((E, N))
         obs, ast, rew, done = env.step_update(rot, ph, jit)
         o_obs, o_ast, o_rew, o_done = orc.step(rot, ph)
-        orc.update(jit)
         same_obs(obs, o_obs, "step %d" % t)
         np.testing.assert_array_equal(_cpu(ast), o_ast.astype(np.float32))
-        np.testing.assert_array_equal(_cpu(rew), o_rew.astype(np.float32))
+        same_reward(rew, o_rew, "step %d" % t)
         np.testing.assert_array_equal(_cpu(done), o_done)
+        orc.update(jit)
         if t in (1, 4):
             obs, ast, rew = env.observe()
             o_obs, o_ast, o_rew = orc.observe()
             same_obs(obs, o_obs, "observation after update %d" % t)
-            np.testing.assert_array_equal(_cpu(rew), o_rew.astype(np.float32))
+            same_reward(rew, o_rew, "observation after update %d" % t)
     from helpers import phero_close
     assert phero_close(_cpu(env.read_state(cm.S_PHERO)), orc.phero, threshold=cfg.phero_threshold).all()
     np.testing.assert_allclose(_cpu(env.read_state(cm.S_ANTS_XYT)), orc.ants_xyt, rtol=0, atol=1e-9)

@@ -157,6 +157,34 @@ def test_fused_step_update_equals_two_calls(torch_mod):
     check_state(b, cfg, F, 39, meta, "fused", (0, 1), True)
 
 
+def _anthill_dist(init, xyt):
+    """All_Rewards.compute_distance (reward_custom.py:59-60) of every ant, float64 [E, N]."""
+    c = np.asarray(init["anthill_xyr"], np.float64)
+    return ((xyt[..., 0] - c[:, None, 0]) ** 2 + (xyt[..., 1] - c[:, None, 1]) ** 2) ** 0.5
+
+
+def _check_reward(cfg, init, got, want, xyt, prev_dist, ctx):
+    """Rewards are bit-exact, with ONE documented exception: All_Rewards' heading term `previous_dist > new_dist`
+    (reward_custom.py:100) on a mathematical TIE.  Ants that start on the anthill centre (radius 0) and turn by a
+    constant angle walk a regular polygon through the centre, so vertex k and vertex n - k are exactly equidistant
+    from it; which way the comparison falls is then decided by the last bit of sin / cos, where the device's
+    `sincos` and the host libm may differ (ant coordinates are held to 1e-9, not to the bit — and numpy's own trig
+    differs between CPUs).  Such an ant may be off by exactly the heading term; anything else fails."""
+    from antsrl_amd import config as cm
+    want32 = want.astype(np.float32)
+    bad = got != want32
+    if not bad.any():
+        return
+    assert cfg.reward_kind == cm.REWARD_ALL, "%s: %d rewards differ" % (ctx, bad.sum())
+    nd = _anthill_dist(init, xyt)
+    # (a last-bit difference of a COORDINATE, whose magnitude is up to the grid size, moves the distance by as much)
+    tie = np.abs(prev_dist - nd) <= 4 * np.spacing(float(max(cfg.w, cfg.h)))
+    step = np.float32(0.1 * cfg.fct_headinganthill)
+    off_by_heading = np.abs(np.abs(got.astype(np.float64) - want) - step) <= 1e-6
+    assert (bad <= (tie & off_by_heading)).all(), "%s: %d rewards differ beyond heading-term ties" % (
+        ctx, (bad & ~(tie & off_by_heading)).sum())
+
+
 def _compare_with_oracle(torch_mod, cfg, init, steps, seed, jitter_mode):
     from antsrl_amd.batched import BatchedAntsEnv
     from antsrl_amd import config as cm
@@ -168,6 +196,7 @@ def _compare_with_oracle(torch_mod, cfg, init, steps, seed, jitter_mode):
     rot, ph = random_actions(cfg, steps, seed)
     rng = np.random.default_rng(seed)
     E = cfg.n_envs
+    prev_dist = _anthill_dist(init, orc.ants_xyt)  # Reward.setup, reward_custom.py:73
     for t in range(steps):
         ctx = "step %d" % t
         obs, ast, rew, done = env.step(rot[t], ph[t])
@@ -176,7 +205,8 @@ def _compare_with_oracle(torch_mod, cfg, init, steps, seed, jitter_mode):
         for e in range(E):
             check_obs(cfg, go[e], o_obs[e], ctx + " env %d" % e)
         np.testing.assert_array_equal(_cpu(ast), o_ast.astype(np.float32), err_msg=ctx)
-        np.testing.assert_array_equal(_cpu(rew), o_rew.astype(np.float32), err_msg=ctx)
+        _check_reward(cfg, init, _cpu(rew), o_rew, orc.ants_xyt, prev_dist, ctx)
+        prev_dist = _anthill_dist(init, orc.ants_xyt)
         np.testing.assert_array_equal(_cpu(done), o_done, err_msg=ctx)
         jit = rng.random((E, cfg.n_ants)) if jitter_mode == "injected" else None
         env.update(jit)
