@@ -31,7 +31,7 @@ REWARD_NONE, REWARD_EXPLORATION, REWARD_FOOD, REWARD_ALL = range(4)
 PHERO_AUTO, PHERO_EXPLICIT_SWEEP = 0, 1
 ACT_AUTO, ACT_CELL_META, ACT_SINGLE_KERNEL = 0, 1, 2
 TIMING_EVENTS = 5  # antsrl_set_timing_events
-Q_CELL_META, Q_SCALED_UNITS, Q_INTERLEAVED, Q_FILTER_SEPARABLE, Q_PERCEIVE_RUN, Q_TIMESTEP = range(6)  # antsrl_query
+Q_CELL_META, Q_SCALED_UNITS, Q_INTERLEAVED, Q_FILTER_SEPARABLE, Q_PERCEIVE_RUN, Q_TIMESTEP, Q_DEFERRED_UPDATE = range(7)  # antsrl_query
 
 (S_ANTS_XYT, S_PREV_XY, S_HOLDING, S_MANDIBLES, S_ACTIVATION, S_PHERO, S_FOOD, S_EXPLORED,
  S_ANTHILL_FOOD, S_ROCK_CENTERS, S_TIMESTEP, S_REWARD_STATE, S_WALLS, S_ANTHILL_AREA,

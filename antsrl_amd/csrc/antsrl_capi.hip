@@ -35,6 +35,9 @@ hipError_t antsrl_launch_move(const KP &p, const int8_t *rot, const int8_t *ph, 
 hipError_t antsrl_launch_perceive(const KP &p, int cur, float *obs, float *agent_state, float *reward, int flags,
                                   uint32_t seq, hipStream_t st);
 hipError_t antsrl_launch_meta_rebase(const KP &p, hipStream_t st);
+bool antsrl_update_move_supported(const KP &p);
+hipError_t antsrl_launch_update_move(const KP &p, int out_buf, double g_dep, double inv_g_dep, const int8_t *rot,
+                                     const int8_t *ph, uint8_t *done, uint32_t seq, hipStream_t st);
 int antsrl_perceive_run(const KP &p);
 hipError_t antsrl_launch_copy16(void *dst, const void *src, size_t bytes, hipStream_t st);
 
@@ -56,6 +59,12 @@ struct AntsHandle {
     hipEvent_t ev[ANTSRL_TIMING_EVENTS]; // measurement hook (antsrl_set_timing_events)
     bool ev_armed;
     uint32_t obs_seq;      // cell-meta path: observations since the explored stamps were last re-based
+    // Deferred update (include/antsrl.h): Environment.update was requested, its host-side bookkeeping is done, its
+    // kernel has NOT been enqueued yet — the next antsrl_step runs it fused with the move (k_update_move); every other
+    // entry point that touches the state enqueues it first (flush_pending).
+    bool pend_update;
+    KP pend_p;             // kernel parameters as they stood at the update's call (g_dep / inv_g_dep differ afterwards)
+    int pend_out_buf;
 };
 
 static thread_local char g_err[512] = "";
@@ -308,7 +317,7 @@ extern "C" int antsrl_create(const AntsCfg *cfg, void *workspace, size_t workspa
     h->cfg = *cfg;
     fill_kp(cfg, &h->p);
     carve(cfg, &h->p.s, (unsigned char *)workspace);
-    h->cur = 0; h->steps_since_update = 0; h->need_full_collect = true; h->is_reset = false;
+    h->cur = 0; h->steps_since_update = 0; h->need_full_collect = true; h->is_reset = false; h->pend_update = false;
     h->sweeps = 0; h->need_wall_clear = false;
     h->has_gen = false; h->episode_seed = 0; h->host_timestep = 1; h->obs_bf16 = false;
     h->ws_bytes = need;
@@ -333,6 +342,7 @@ extern "C" int antsrl_reset(AntsHandle *h, const AntsInit *init, void *stream)
     if (!init->ants_xyt || !init->seed || !init->walls || !init->food || !init->anthill_xyr)
         return fail(ANTSRL_E_INVALID, "AntsInit: ants_xyt, seed, walls, food, anthill_xyr are required");
     if (h->p.R > 0 && !init->rocks) return fail(ANTSRL_E_INVALID, "AntsInit.rocks is NULL but n_rocks > 0");
+    h->pend_update = false; // (a deferred update of the state being replaced)
     hipError_t e = antsrl_launch_reset(h->p, init, (hipStream_t)stream);
     if (e != hipSuccess) return hip_fail(e, "reset");
     h->p.deposit_strength = h->cfg.deposit_strength;
@@ -345,6 +355,7 @@ extern "C" int antsrl_reset(AntsHandle *h, const AntsInit *init, void *stream)
 
 static int do_generate(AntsHandle *h, uint64_t seed, hipStream_t st)
 {
+    h->pend_update = false; // (a deferred update of the state being replaced)
     hipError_t e = antsrl_launch_generate(h->p, h->gen, seed, st);
     if (e != hipSuccess) return hip_fail(e, "generate");
     h->p.deposit_strength = h->cfg.deposit_strength;
@@ -403,6 +414,17 @@ extern "C" int antsrl_set_obs_format(AntsHandle *h, int format)
     return ANTSRL_OK;
 }
 
+static int hip_fail(hipError_t e, const char *what);
+// Enqueues a deferred update on its own (k_update_one), e.g. ahead of a state read.
+static int flush_pending(AntsHandle *h, hipStream_t st)
+{
+    if (!h->pend_update) return ANTSRL_OK;
+    h->pend_update = false;
+    hipError_t e = antsrl_launch_update(h->pend_p, nullptr, h->pend_out_buf, st);
+    if (e != hipSuccess) return hip_fail(e, "deferred update");
+    return ANTSRL_OK;
+}
+
 static int not_reset() { return fail(ANTSRL_E_INVALID, "antsrl_reset has not been called on this handle"); }
 
 // One observation on the cell-meta path: k_move (with the action phases when `stepping`) then k_perceive.
@@ -416,8 +438,16 @@ static int meta_observe(AntsHandle *h, const int8_t *rot, const int8_t *ph, floa
         h->obs_seq = 0;
     }
     h->obs_seq++;
-    e = antsrl_launch_move(h->p, rot, ph, done, stepping ? 1 : 0, h->obs_seq, st);
-    if (e != hipSuccess) return hip_fail(e, "move");
+    if (h->pend_update && stepping) { // the previous step's update and this step's move in one launch
+        h->pend_update = false;
+        e = antsrl_launch_update_move(h->p, h->pend_out_buf, h->pend_p.g_dep, h->pend_p.inv_g_dep, rot, ph, done, h->obs_seq, st);
+        if (e != hipSuccess) return hip_fail(e, "update + move");
+    } else {
+        int rc = flush_pending(h, st);
+        if (rc) return rc;
+        e = antsrl_launch_move(h->p, rot, ph, done, stepping ? 1 : 0, h->obs_seq, st);
+        if (e != hipSuccess) return hip_fail(e, "move");
+    }
     if (timed) (void)hipEventRecord(h->ev[2], st);
     e = antsrl_launch_perceive(h->p, h->cur, obs, agent_state, reward,
                                (stepping ? ACT_STEP : 0) | (obs ? ACT_HAS_OBS : 0) | (obs && h->obs_bf16 ? ACT_OBS_BF16 : 0),
@@ -452,9 +482,11 @@ static int do_step(AntsHandle *h, const int8_t *rot, const int8_t *ph, float *ob
 }
 
 static int do_update(AntsHandle *h, const double *jitter, hipStream_t st, bool sweep_done,
-                     bool update_fused = false)
+                     bool update_fused = false, bool may_defer = false)
 {
     hipError_t e;
+    int frc = flush_pending(h, st); // (two updates in a row)
+    if (frc) return frc;
     if (h->p.scaled) {
         if (h->p.g_dep < 1e-20) { // re-base the units long before u = v / f0^S can overflow fp32
             e = antsrl_launch_phero_renorm(h->p, st);
@@ -473,8 +505,16 @@ static int do_update(AntsHandle *h, const double *jitter, hipStream_t st, bool s
         if (e != hipSuccess) return hip_fail(e, "pheromone sweep");
     }
     if (!update_fused) {
-        e = antsrl_launch_update(h->p, jitter, h->p.scaled ? 0 : h->cur ^ 1, st);
-        if (e != hipSuccess) return hip_fail(e, "update");
+        // Deferred: with the library's own wall jitter (no caller buffer to outlive the call) and nothing that has to
+        // run after the update kernel in this call, the kernel is left for the next step's k_update_move.
+        if (may_defer && !jitter && !h->need_full_collect && antsrl_update_move_supported(h->p)) {
+            h->pend_update = true;
+            h->pend_p = h->p;
+            h->pend_out_buf = h->p.scaled ? 0 : h->cur ^ 1;
+        } else {
+            e = antsrl_launch_update(h->p, jitter, h->p.scaled ? 0 : h->cur ^ 1, st);
+            if (e != hipSuccess) return hip_fail(e, "update");
+        }
     }
     if (h->p.scaled) {
         h->sweeps++;
@@ -518,7 +558,7 @@ extern "C" int antsrl_update(AntsHandle *h, const double *wall_jitter, void *str
 {
     if (!h) return fail(ANTSRL_E_INVALID, "NULL handle");
     if (!h->is_reset) return not_reset();
-    return do_update(h, wall_jitter, (hipStream_t)stream, false);
+    return do_update(h, wall_jitter, (hipStream_t)stream, false, false, true);
 }
 
 extern "C" int antsrl_step_update(AntsHandle *h, const int8_t *rotation, const int8_t *phero,
@@ -557,9 +597,10 @@ extern "C" int antsrl_step_update(AntsHandle *h, const int8_t *rotation, const i
     if (rc) return rc;
     if (timed) (void)hipEventRecord(h->ev[3], st);
     const bool was_done = h->host_timestep == h->cfg.max_time; // RL_api.py:200, same for every env
-    rc = do_update(h, wall_jitter, st, true, fuse);
+    const bool regen = was_done && h->has_gen && h->gen.auto_reset;
+    rc = do_update(h, wall_jitter, st, true, fuse, !regen);
     if (timed) (void)hipEventRecord(h->ev[4], st);
-    if (rc == ANTSRL_OK && was_done && h->has_gen && h->gen.auto_reset)
+    if (rc == ANTSRL_OK && regen)
         // next episode, like main.py:69-79 does per episode (reference streams: env e takes seed + e, so the next
         // episode starts E seeds further)
         rc = do_generate(h, h->episode_seed + (h->gen.rng_kind == ANTSRL_RNG_REFERENCE ? (uint64_t)h->p.E : 1u), st);
@@ -576,6 +617,7 @@ extern "C" int antsrl_query(const AntsHandle *h, int what, long long *value)
     case ANTSRL_Q_FILTER_SEPARABLE: *value = h->p.filter_sep; break;
     case ANTSRL_Q_PERCEIVE_RUN: *value = h->p.meta ? antsrl_perceive_run(h->p) : 0; break;
     case ANTSRL_Q_TIMESTEP: *value = h->host_timestep; break;
+    case ANTSRL_Q_DEFERRED_UPDATE: *value = antsrl_update_move_supported(h->p); break;
     default: return fail(ANTSRL_E_INVALID, "bad query selector %d", what);
     }
     return ANTSRL_OK;
@@ -603,6 +645,8 @@ extern "C" int antsrl_set_activation(AntsHandle *h, const float *act, double new
 {
     if (!h || !act) return fail(ANTSRL_E_INVALID, "NULL handle or act");
     if (!h->is_reset) return not_reset();
+    int frc = flush_pending(h, (hipStream_t)stream); // (the deferred update deposits with the activation as it was)
+    if (frc) return frc;
     hipError_t e = antsrl_launch_set_activation(h->p, act, (hipStream_t)stream);
     if (e != hipSuccess) return hip_fail(e, "set_activation");
     if (new_deposit_strength > 0) h->p.deposit_strength = new_deposit_strength;
@@ -668,6 +712,8 @@ extern "C" int antsrl_read_state(AntsHandle *h, int which, void *dst, void *stre
     if (!h->is_reset) return not_reset();
     if (which < 0 || which >= ANTSRL_S_COUNT_) return fail(ANTSRL_E_INVALID, "bad state selector %d", which);
     if (state_bytes(h, which) == 0) return ANTSRL_OK;
+    int frc = flush_pending(h, (hipStream_t)stream);
+    if (frc) return frc;
     hipError_t e = antsrl_launch_read_state(h->p, which, h->cur, dst, (hipStream_t)stream);
     if (e != hipSuccess) return hip_fail(e, "read_state");
     return ANTSRL_OK;

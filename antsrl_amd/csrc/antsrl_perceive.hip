@@ -17,6 +17,7 @@
 // No MFMA: nothing on this path is a dense contraction.  Host launchers at the end.
 #include "antsrl_util.h"
 #include "antsrl_flush.h"
+#include "antsrl_update_one.h"
 
 #define PRC_UNROLL 2 // ants in flight per wave (all their gathers are issued before the first is consumed)
 
@@ -32,11 +33,9 @@ __host__ __device__ inline size_t move_lds_bytes(int HT, int N)
 }
 
 template <int C>
-__global__ void __launch_bounds__(1024)
-k_move(const KP p, const int8_t *__restrict__ rotation, const int8_t *__restrict__ phero_act,
-       uint8_t *__restrict__ done, const int do_step, const uint32_t seq)
+__device__ __forceinline__ void move_body(const KP &p, const int8_t *__restrict__ rotation, const int8_t *__restrict__ phero_act,
+                                          uint8_t *__restrict__ done, const int do_step, const uint32_t seq, unsigned char *smem)
 {
-    extern __shared__ __align__(16) unsigned char smem[];
     const int e = blockIdx.x, tid = threadIdx.x, T = blockDim.x;
     const int N = p.N, W = p.W, H = p.H, K = p.K;
     const size_t G = (size_t)W * H, eN = (size_t)e * N;
@@ -168,6 +167,32 @@ k_move(const KP p, const int8_t *__restrict__ rotation, const int8_t *__restrict
         const uint32_t cell = (uint32_t)(wrap_index((int)x, W) * H + wrap_index((int)y, H));
         pres[(size_t)cell * FS2] = (uint16_t)seq;
     }
+}
+
+template <int C>
+__global__ void __launch_bounds__(1024)
+k_move(const KP p, const int8_t *__restrict__ rotation, const int8_t *__restrict__ phero_act,
+       uint8_t *__restrict__ done, const int do_step, const uint32_t seq)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    move_body<C>(p, rotation, phero_act, done, do_step, seq, smem);
+}
+
+// Environment.update of step t (deferred by the host, include/antsrl.h "deferred update") and the move of step t + 1
+// in ONE launch: both are one-workgroup-per-environment, one-ant-per-thread kernels bound by scattered line traffic,
+// and the second re-reads what the first has just written — the ant's state and the record of its cell (the deposit
+// cell IS the food cell of the next mandible decision).  Back to back in one workgroup those reads are L1 / L2 hits
+// instead of HBM fetches, and one launch ramp and tail go away.  Same device functions as k_update_one / k_move:
+// the results are bit-identical to the two launches (tests/test_gpu_parity.py::test_deferred_update_is_bit_identical).
+template <int C>
+__global__ void __launch_bounds__(1024)
+k_update_move(const KP p, const int out_buf, const double g_dep, const double inv_g_dep, const int8_t *__restrict__ rotation,
+              const int8_t *__restrict__ phero_act, uint8_t *__restrict__ done, const uint32_t seq)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    update_one_body<C>(p, nullptr, out_buf, smem, g_dep, inv_g_dep);
+    __syncthreads(); // the update's global writes are visible to the whole workgroup; its LDS is dead
+    move_body<C>(p, rotation, phero_act, done, 1, seq, smem);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -708,6 +733,29 @@ hipError_t antsrl_launch_move(const KP &p, const int8_t *rot, const int8_t *ph, 
         seen[dev] = lds;
     }
     hipLaunchKernelGGL((k_move<2>), dim3(p.E), dim3(T), lds, st, p, rot, ph, done, do_step, seq);
+    return hipGetLastError();
+}
+
+// The deferred update of the previous step + this step's move in one launch (see k_update_move).
+bool antsrl_update_move_supported(const KP &p)
+{
+    return p.meta && p.scaled && p.C == 2 && p.N <= 1024 && !PROF_ENV("ANTSRL_NO_DEFER_UPDATE");
+}
+
+hipError_t antsrl_launch_update_move(const KP &p, int out_buf, double g_dep, double inv_g_dep, const int8_t *rot,
+                                     const int8_t *ph, uint8_t *done, uint32_t seq, hipStream_t st)
+{
+    const int T = (p.N + 63) / 64 * 64;
+    const size_t lds = std::max(update_one_lds_bytes(p.HT, p.R, T / 64, p.N), move_lds_bytes(p.HT, p.N));
+    static size_t seen[ANTSRL_MAX_DEVICES] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= ANTSRL_MAX_DEVICES) return hipErrorInvalidDevice;
+    if (lds > 64 * 1024 && lds > seen[dev]) {
+        hipError_t err = hipFuncSetAttribute((const void *)k_update_move<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (err != hipSuccess) return err;
+        seen[dev] = lds;
+    }
+    hipLaunchKernelGGL((k_update_move<2>), dim3(p.E), dim3(T), lds, st, p, out_buf, g_dep, inv_g_dep, rot, ph, done, seq);
     return hipGetLastError();
 }
 

@@ -2,6 +2,7 @@
 // (per-phase loops, any N), k_update_one (one ant per thread, N <= 1024), k_collect_full, launchers.
 #include "antsrl_util.h"
 #include "antsrl_update_env.h"
+#include "antsrl_update_one.h"
 
 template <int C>
 __global__ void __launch_bounds__(1024)
@@ -11,226 +12,12 @@ k_update(const KP p, const double *__restrict__ wall_jitter, const int out_buf)
     update_env<C>(p, blockIdx.x, wall_jitter, out_buf, smem);
 }
 
-// LDS of k_update_one: hash [HT] keys + values, rock table [R][4] + new centres [R][2], reduction and
-// scan scratch per wave, ants' x / y [N].
-__host__ __device__ inline size_t update_one_lds_bytes(int HT, int R, int nwaves, int N)
-{
-    return align_up(8 * (size_t)HT, 16) + 48 * (size_t)(R > 0 ? R : 1) + 8 * (size_t)nwaves +
-           align_up(4 * (size_t)nwaves, 8) + 16 * (size_t)N + 16;
-}
-
-// k_update for N <= 1024: ONE ant per thread.  Same phases and the same arithmetic as update_env,
-// restructured around latency: every independent global load of the ant (position, previous position,
-// reward tint, activation, the two sparse-update cells) is issued before anything waits; the ant's
-// state then stays in registers across the phases, the rock pass reads all ants' positions from LDS,
-// and each array is written back once.  update_env re-reads x / y from HBM in every phase (a dependent
-// round trip behind each barrier) — it remains the path for N > 1024 and for the fused launch.
 template <int C>
 __global__ void __launch_bounds__(1024)
 k_update_one(const KP p, const double *__restrict__ wall_jitter, const int out_buf)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    const int e = blockIdx.x, tid = threadIdx.x, T = blockDim.x;
-    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwaves = T >> 6;
-    const int N = p.N, W = p.W, H = p.H, R = p.R;
-    const size_t G = (size_t)W * H, eN = (size_t)e * N;
-    uint32_t *hkeys = (uint32_t *)smem, *hvals = hkeys + p.HT;
-    double *rock = (double *)(smem + align_up(8 * (size_t)p.HT, 16)); // [R][4] cx, cy, radius, weight
-    double *rk = rock + 4 * (R > 0 ? R : 1);                          // [R][2] new centres
-    double *red = rk + 2 * (R > 0 ? R : 1);                           // [nwaves]
-    uint32_t *wave_tot = (uint32_t *)(red + nwaves);                  // [nwaves]
-    double *sx = (double *)((unsigned char *)wave_tot + align_up(4 * (size_t)nwaves, 8)), *sy = sx + N;
-
-    const uint32_t *walls = p.s.walls_bits + (size_t)e * p.words;
-    const FoodView food{p.s.food + (size_t)e * G * p.fs, p.fs};
-    const size_t PS = (size_t)p.ps; // floats per cell of the pheromone array
-    float *out = p.s.phero[out_buf] + (size_t)e * G * PS;
-    const bool on = tid < N;
-    const size_t a = eN + (on ? tid : 0);
-
-    // ---- every independent load first
-    double x = p.s.x[a], y = p.s.y[a];
-    const double px0 = p.s.prev_x[a], py0 = p.s.prev_y[a]; // used on a wall hit only; prefetched all the same
-    const uint8_t rstate = p.s.reward_state[a];
-    const double theta0 = p.s.theta[a]; // used on a wall hit only
-    float act[C];
-#pragma unroll
-    for (int c = 0; c < C; ++c) act[c] = p.s.activation[a * C + c];
-    // (unconditional loads on the clamped index + selects: a load inside a per-lane branch is followed by
-    // its own s_waitcnt vmcnt(0))
-    const int32_t wc_l = p.s.walldep_cell[a], dc_l = p.s.dirty_cell[a];
-    const int32_t wc = (p.scaled && on) ? wc_l : -1;
-    const int32_t dc = on ? dc_l : -1;
-    const int ts = p.s.timestep[e] + 1; // environment.py:45
-    if (tid < R) {
-        rock[4 * tid + 0] = p.s.rock_cx[(size_t)e * R + tid];
-        rock[4 * tid + 1] = p.s.rock_cy[(size_t)e * R + tid];
-        rock[4 * tid + 2] = p.s.rock_r[(size_t)e * R + tid];
-        rock[4 * tid + 3] = p.s.rock_w[(size_t)e * R + tid];
-    }
-    for (int h = tid; h < p.HT; h += T) {
-        hkeys[h] = HASH_EMPTY;
-        hvals[h] = 0u;
-    }
-    const float food_dc_l = food[dc_l >= 0 ? dc_l : 0]; // nobody else touches a dirty cell during the update
-    const float food_dc = dc >= 0 ? food_dc_l : 0.0f;
-
-    // ---- Walls.update, walls.py:25-28
-    const bool hit = on && test_bit(walls, (uint32_t)((int)x * H + (int)y));
-    double u = 0.0;
-    if (wall_jitter) { // k-th colliding ant (index order) takes the k-th draw
-        uint32_t tot;
-        const uint32_t rank = block_excl_scan_flag(hit, wave_tot, lane, wave, nwaves, &tot);
-        if (hit) u = wall_jitter[eN + rank];
-    } else if (hit) {
-        u = jitter_u01(p.rng_seed, (uint32_t)e, (uint32_t)ts, (uint32_t)tid);
-    }
-    bool moved = hit;
-    if (hit) {
-        x = px0;
-        y = py0;
-        p.s.theta[a] = theta0 + (u - 0.5); // theta is NOT re-wrapped here
-    }
-
-    // ---- CircleObstacles.update, circle_obstacles.py:35-58
-    if (R > 0) {
-        if (on) {
-            sx[tid] = x;
-            sy[tid] = y;
-        }
-        __syncthreads();
-        // pass 1: centres -= sum_over_ants(push)/weight, ants summed in index order (colliding ones only:
-        // the others contribute exact zeros)
-        for (int q = wave; q < R; q += nwaves) {
-            const double cx = rock[4 * q + 0], cy = rock[4 * q + 1], rad = rock[4 * q + 2];
-            const double rad2_hi = rad * rad * (1.0 + 1e-12) + 1e-300; // d2 above this: sqrt(d2) > rad for sure
-            double sumx = 0.0, sumy = 0.0;
-            for (int base = 0; base < N; base += 64) {
-                const int i = base + lane;
-                double px = 0.0, py = 0.0;
-                bool col = false;
-                if (i < N) {
-                    const double vx = cx - sx[i], vy = cy - sy[i];
-                    const double d2 = vx * vx + vy * vy;
-                    if (!(d2 > rad2_hi)) {
-                        const double d = sqrt(d2);
-                        const double f = 1 - rad / (d + 0.001);
-                        px = vx * f; py = vy * f;
-                        col = !(d > rad);
-                    }
-                }
-                unsigned long long m = __ballot(col);
-                while (m) {
-                    const int l = __builtin_ctzll(m);
-                    m &= m - 1;
-                    sumx += __shfl(px, l);
-                    sumy += __shfl(py, l);
-                }
-            }
-            if (lane == 0) {
-                rk[2 * q + 0] = cx - sumx / rock[4 * q + 3];
-                rk[2 * q + 1] = cy - sumy / rock[4 * q + 3];
-            }
-        }
-        __syncthreads();
-        if (tid < R) {
-            p.s.rock_cx[(size_t)e * R + tid] = rk[2 * tid + 0];
-            p.s.rock_cy[(size_t)e * R + tid] = rk[2 * tid + 1];
-        }
-        // pass 2 (:53-58): ants pushed out of the UPDATED rocks, then warp_xy
-        double ax = 0.0, ay = 0.0;
-        for (int q = 0; q < R; ++q) {
-            const double vx = rk[2 * q + 0] - x, vy = rk[2 * q + 1] - y;
-            const double rad = rock[4 * q + 2];
-            const double d2 = vx * vx + vy * vy;
-            if (d2 > rad * rad * (1.0 + 1e-12) + 1e-300) continue; // adds an exact +0.0
-            const double d = sqrt(d2);
-            const double f = 1 - rad / (d + 0.001);
-            double px = vx * f, py = vy * f;
-            if (d > rad) { px = 0.0; py = 0.0; }
-            ax += px; ay += py;
-        }
-        x = warp_coord(x + ax, (double)W);
-        y = warp_coord(y + ay, (double)H);
-        moved = true;
-    }
-
-    // ---- Ants.update, ants.py:123-130: prev := cur; deposit (pheromone.py:36-41)
-    __syncthreads(); // the hash table is initialised (R == 0 and library jitter: no barrier so far)
-    const uint32_t cell = (uint32_t)((int)x * H + (int)y);
-    // the deposit cell's old values, loaded by every ant ahead of the barriers (only the cell's winner uses
-    // them; no other ant writes this cell in this update except the wall-deposit clear, and a deposit on a
-    // wall cell ignores the old value)
-    float pold[C];
-#pragma unroll
-    for (int c = 0; c < C; ++c) pold[c] = out[(size_t)cell * PS + c];
-    if (on) {
-        if (moved) {
-            p.s.x[a] = x;
-            p.s.y[a] = y;
-        }
-        p.s.prev_x[a] = x;
-        p.s.prev_y[a] = y;
-        lww_insert(hkeys, hvals, (uint32_t)p.HT - 1, cell, (uint32_t)tid);
-        p.s.reward_state[a] = (uint8_t)((double)rstate * 0.9); // :130
-    }
-    __syncthreads();
-    if (p.scaled) {
-        // a deposit that landed on a WALL cell in the previous update is zeroed by this update's Walls
-        // pass (walls.py:30), before this update's deposits
-        if (wc >= 0) {
-            for (int c = 0; c < C; ++c) out[(size_t)wc * PS + c] = 0.0f;
-            p.s.walldep_cell[a] = -1;
-        }
-        __syncthreads();
-    }
-    double gain = 0.0;
-    if (on) {
-        if (lww_winner(hkeys, hvals, (uint32_t)p.HT - 1, cell) == (uint32_t)tid) {
-            if (!p.scaled) {
-#pragma unroll
-                for (int c = 0; c < C; ++c) {
-                    if (act[c] != 0.0f) {
-                        float v = pold[c] + act[c];
-                        if (p.has_max_val) v = fminf(v, (float)p.max_val);
-                        out[(size_t)cell * PS + c] = v;
-                    }
-                }
-            } else { // scaled units, see update_env
-                const bool on_wall = test_bit(walls, cell);
-                bool wrote = false;
-#pragma unroll
-                for (int c = 0; c < C; ++c) {
-                    if (act[c] != 0.0f) {
-                        double v = (double)pold[c] * p.g_dep;
-                        if (v < p.threshold || on_wall) v = 0.0;
-                        v += (double)act[c];
-                        if (p.has_max_val) v = fmin(v, p.max_val);
-                        out[(size_t)cell * PS + c] = (float)(v * p.inv_g_dep);
-                        wrote = true;
-                    } else if (on_wall) {
-                        out[(size_t)cell * PS + c] = 0.0f;
-                    }
-                }
-                if (on_wall && wrote) p.s.walldep_cell[a] = (int32_t)cell;
-            }
-        }
-        // ---- Anthill.update (anthill.py:41-46), sparse form
-        if (dc >= 0) {
-            gain = (double)food_dc;
-            food[dc] = 0.0f;
-            p.s.dirty_cell[a] = -1;
-        }
-    }
-    for (int o = 32; o > 0; o >>= 1) gain += __shfl_down(gain, o);
-    if (lane == 0) red[wave] = gain;
-    __syncthreads();
-    if (tid == 0) {
-        double s2 = 0.0;
-        for (int w = 0; w < nwaves; ++w) s2 += red[w];
-        if (s2 != 0.0) p.s.anthill_food[e] += s2;
-        p.s.timestep[e] = ts;
-    }
+    update_one_body<C>(p, wall_jitter, out_buf, smem, p.g_dep, p.inv_g_dep);
 }
 
 // Anthill.update over the WHOLE grid (anthill.py:41-46): needed on the first update after a

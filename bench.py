@@ -324,13 +324,19 @@ def main():
         ab = algorithmic_bytes(cfg.n_ants, cfg.w, cfg.h, cfg.n_phero, cfg.n_channels, obs_bytes=obs_bytes)
         meta_path = bool(env.query(cm.Q_CELL_META))
         scaled = bool(env.query(cm.Q_SCALED_UNITS))
+        deferred = bool(env.query(cm.Q_DEFERRED_UPDATE)) and cfg.n_ants <= 1024
         kern = {}
         tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.config)
         traffic_rec = json.load(open(tpath)) if os.path.exists(tpath) else {}
         if timing:
             ms = np.array([[evs.elapsed_ms(NEV * j + i, NEV * j + i + 1) for i in range(NEV - 1)]
                            for j in range(len(timed_steps))])
-            if meta_path:
+            if meta_path and deferred:
+                # antsrl_update is deferred into the next step: [1]..[2] brackets k_update_move (the previous step's
+                # update + this step's move), [3]..[4] is empty (include/antsrl.h)
+                kern = dict(sweep=float(ms[:, 0].mean()), update_move=float(ms[:, 1].mean()), perceive=float(ms[:, 2].mean()))
+                ab["update_move"] = ab["move"] + ab["update"]
+            elif meta_path:
                 kern = dict(sweep=float(ms[:, 0].mean()), move=float(ms[:, 1].mean()), perceive=float(ms[:, 2].mean()),
                             update=float(ms[:, 3].mean()))
             else:
@@ -342,7 +348,7 @@ def main():
                           "k_sweep_r1x2" if cfg.filter_radius == 1 and cfg.n_phero == 2 and cfg.h % 2 == 0 else
                           "k_sweep_sep2" if cfg.n_phero == 2 and cfg.h % 2 == 0 and env.query(cm.Q_FILTER_SEPARABLE) else
                           "k_sweep_march")
-            names = dict(sweep=sweep_name, act="k_act", move="k_move",
+            names = dict(sweep=sweep_name, act="k_act", move="k_move", update_move="k_update_move",
                          perceive="k_perceive", update="k_update_one" if cfg.n_ants <= 1024 else "k_update")
             achieved = ab[dom] * E / (kern[dom] * 1e-3) / 1e9
             # PMC-derived HBM bytes per launch: NOT measured in this run (rocprofv3 --pmc needs its own passes,
@@ -383,8 +389,10 @@ def main():
                        "filter_separable": bool(env.query(cm.Q_FILTER_SEPARABLE)) if cfg.filter_radius else None,
                        "reward": "ExplorationReward", "obs_dtype": obs_dtype,
                        "pheromone_update": "scaled units (no per-step sweep)" if scaled else "explicit sweep kernel",
-                       "kernels": ("k_move + k_perceive (cell-meta layout, %d ants per wave) + " % env.query(cm.Q_PERCEIVE_RUN)
-                                   if meta_path else "k_act + ") + ("k_update_one" if cfg.n_ants <= 1024 else "k_update"),
+                       "kernels": ("k_update_move (the previous step's update + this step's move, one launch) + k_perceive "
+                                   "(cell-meta layout, %d ants per wave)" % env.query(cm.Q_PERCEIVE_RUN)) if meta_path and deferred
+                       else (("k_move + k_perceive (cell-meta layout, %d ants per wave) + " % env.query(cm.Q_PERCEIVE_RUN)
+                              if meta_path else "k_act + ") + ("k_update_one" if cfg.n_ants <= 1024 else "k_update")),
                        "policy": ("linear DQN net (F+2 -> 32 -> 3+3) in-loop, bf16 MFMA" if policy is not None
                                   else "uniform random, pre-generated on device"),
                        "parallelism": "env-sharded x%d, reward/done all-gather (%s)" % (world, args.gather)},

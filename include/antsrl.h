@@ -280,7 +280,15 @@ int antsrl_observe(AntsHandle *h, float *obs, float *agent_state, float *reward,
  *   wall_jitter  double [E][N] or NULL.  When given, entry k of env e is the k-th
  *   value np.random.random(k) would have returned in Walls.update (walls.py:28):
  *   the k-th colliding ant, in ant-index order, consumes it.  NULL = built-in
- *   counter-based generator (AntsCfg.rng_seed). */
+ *   counter-based generator (AntsCfg.rng_seed).
+ * DEFERRED UPDATE.  With wall_jitter == NULL on the cell-meta path (scaled pheromone units, <= 1024 ants,
+ * ANTSRL_Q_DEFERRED_UPDATE) the call does the update's bookkeeping and returns without enqueuing its kernel: the
+ * next antsrl_step / antsrl_step_update runs it in the same launch as its move (k_update_move: the move re-reads
+ * what the update has just written — one launch and most of the second kernel's HBM fetches saved).  Every other
+ * entry point that reads or replaces the state (antsrl_observe, antsrl_read_state, antsrl_set_activation, a second
+ * antsrl_update, antsrl_reset / antsrl_generate) enqueues or drops it first, on ITS stream argument: results are
+ * the same as with an immediate launch, bit for bit; only the moment the kernel is enqueued moves.  Callers that
+ * alternate streams between calls must order them as they already have to for the state itself. */
 int antsrl_update(AntsHandle *h, const double *wall_jitter, void *stream);
 
 /* main.py:98 followed by main.py:131 — one full simulation step. */
@@ -293,7 +301,8 @@ int antsrl_step_update(AntsHandle *h, const int8_t *rotation, const int8_t *pher
  * While set, the NEXT antsrl_step_update records them on its stream: [0] before the pheromone sweep,
  * [1] after it, [2] after the per-ant action kernel (k_move; equal to [1] where one kernel does both),
  * [3] after the perception kernel (k_perceive / k_act), [4] after the update kernel; the hook then
- * clears itself. */
+ * clears itself.  With a deferred update (antsrl_update) [1]..[2] brackets k_update_move — the PREVIOUS step's
+ * update and this step's move — and [3]..[4] is empty. */
 #define ANTSRL_TIMING_EVENTS 5
 int antsrl_set_timing_events(AntsHandle *h, void *const *events);
 
@@ -307,6 +316,7 @@ enum {
     ANTSRL_Q_PERCEIVE_RUN = 4,     /* ants per wave of k_perceive (0 without the cell-meta path)          */
     ANTSRL_Q_TIMESTEP = 5,         /* Environment.timestep (environment.py:27,45) as the host mirrors it: every env of a
                                       handle steps in lockstep, so no device read is needed                */
+    ANTSRL_Q_DEFERRED_UPDATE = 6,  /* 1: antsrl_update(NULL jitter) is deferred into the next step (k_update_move) */
     ANTSRL_Q_COUNT_
 };
 int antsrl_query(const AntsHandle *h, int what, long long *value);

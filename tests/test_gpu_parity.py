@@ -413,6 +413,60 @@ def test_stencil_shapes_vs_oracle(torch_mod, radius, separable, W, H):
     _compare_with_oracle(torch_mod, cfg, synth_init(cfg, seed=W + H), steps=5, seed=radius, jitter_mode="builtin")
 
 
+@pytest.mark.parametrize("E,N,W,H,rocks", [(6, 512, 256, 256, 8), (3, 100, 64, 48, 2), (2, 1024, 128, 128, 0), (5, 37, 40, 40, 3)])
+def test_deferred_update_is_bit_identical(torch_mod, E, N, W, H, rocks):
+    """antsrl_update with the library's own wall jitter is deferred into the next step (k_update_move, include/antsrl.h
+    "DEFERRED UPDATE").  Handle A runs the loop the way bench.py and main.py do (the update kernel always rides with
+    the next move); handle B reads a state array after every update, which enqueues the deferred update at once
+    (k_update_one, then k_move on its own at the next step).  Every output of every step and the final state must be
+    the same bit for bit — and equal to the oracle's.  Steps without rotation / pheromone actions and a standalone
+    observation (which also flushes) are mixed in."""
+    from antsrl_amd import config as cm
+    from antsrl_amd.batched import BatchedAntsEnv
+    from antsrl_amd.synth import random_actions, synth_init
+    from oracle.oracle import Oracle
+    cfg = cm.make_cfg(E, N, W, H, n_rocks=rocks, deposit_strength=256.0, reward_kind=cm.REWARD_ALL, act_path=cm.ACT_CELL_META)
+    init = synth_init(cfg, seed=31 + N, wall_density=0.08)
+    a, b = BatchedAntsEnv(cfg), BatchedAntsEnv(cfg)
+    assert a.query(cm.Q_DEFERRED_UPDATE) == 1
+    a.reset(init)
+    b.reset(init)
+    orc = Oracle(cfg, init, n_threads=4)
+    steps = 14
+    rot, ph = random_actions(cfg, steps, seed=3)
+    for t in range(steps):
+        r = rot[t] if t != 5 else None
+        q = ph[t] if t != 8 else None
+        if t % 2 == 0:  # one call per step / the reference's two calls
+            oa = [x.clone() for x in a.step_update(r, q, None)]
+            ob = [x.clone() for x in b.step_update(r, q, None)]
+        else:
+            oa = [x.clone() for x in a.step(r, q)]
+            a.update(None)
+            ob = [x.clone() for x in b.step(r, q)]
+            b.update(None)
+        b.read_state(cm.S_TIMESTEP)  # B: the deferred update is enqueued now, on its own
+        oo = orc.step(r, q)
+        orc.update(None)
+        for x, y in zip(oa, ob):
+            assert torch_mod.equal(x, y), "step %d" % t
+        np.testing.assert_array_equal(_cpu(oa[2]), oo[2].astype(np.float32), err_msg="reward, step %d" % t)
+        np.testing.assert_array_equal(_cpu(oa[3]), oo[3], err_msg="done, step %d" % t)
+        if t == 9:  # a standalone observation between an update and the next step (main.py:88)
+            xa, xb = a.observe(), b.observe()
+            orc.observe()
+            for x, y in zip(xa, xb):
+                assert torch_mod.equal(x, y)
+    for which in (cm.S_ANTS_XYT, cm.S_PREV_XY, cm.S_HOLDING, cm.S_MANDIBLES, cm.S_PHERO, cm.S_FOOD, cm.S_EXPLORED,
+                  cm.S_ANTHILL_FOOD, cm.S_TIMESTEP, cm.S_REWARD_STATE) + ((cm.S_ROCK_CENTERS,) if rocks else ()):
+        assert torch_mod.equal(a.read_state(which), b.read_state(which)), which
+    np.testing.assert_allclose(_cpu(a.read_state(cm.S_ANTS_XYT)), orc.ants_xyt, rtol=0, atol=XY_ATOL)
+    np.testing.assert_array_equal(_cpu(a.read_state(cm.S_FOOD)), orc.food)
+    np.testing.assert_array_equal(_cpu(a.read_state(cm.S_EXPLORED)), orc.explored)
+    np.testing.assert_array_equal(_cpu(a.read_state(cm.S_ANTHILL_FOOD)), orc.anthill_food)
+    assert phero_close(_cpu(a.read_state(cm.S_PHERO)), orc.phero, threshold=cfg.phero_threshold).all()
+
+
 def test_scaled_units_edge_cases(torch_mod):
     """Scaled pheromone units against the oracle where they need care: an initial grid with
     pheromone on wall cells, ants that START on wall cells (their deposits live for exactly one
