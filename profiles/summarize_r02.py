@@ -38,6 +38,8 @@ for cfg in ("c3", "c2", "c4", "c5"):
             if k.startswith("k_") and not k.startswith(("k_reset", "k_gen", "k_collect", "k_copy", "k_read", "k_policy_w")):
                 agg[(k, r["Counter_Name"])].append(float(r["Counter_Value"]))
         for (k, c), v in agg.items():
+            if len(v) < 5:  # a kernel launched once or twice per run (the first step's k_move, the first update's k_update_one)
+                continue
             t = v[-15:]
             per.setdefault(k, {})[c] = sum(t) / len(t)
     if per:
