@@ -33,7 +33,10 @@ bool antsrl_meta_supported(const KP &p);
 hipError_t antsrl_launch_move(const KP &p, const int8_t *rot, const int8_t *ph, uint8_t *done, int do_step, uint32_t seq,
                               hipStream_t st);
 hipError_t antsrl_launch_perceive(const KP &p, int cur, float *obs, float *agent_state, float *reward, int flags,
-                                  uint32_t seq, hipStream_t st);
+                                  uint32_t seq, hipStream_t st, const PolArgs *pol);
+bool antsrl_inloop_policy_supported(const KP &p);
+hipError_t antsrl_launch_policy_pack(unsigned char *pack, const float *w1, const float *b1, const float *w2, const float *b2,
+                                     const float *w3, const float *b3, int F, hipStream_t st);
 hipError_t antsrl_launch_meta_rebase(const KP &p, hipStream_t st);
 bool antsrl_update_move_supported(const KP &p);
 hipError_t antsrl_launch_update_move(const KP &p, int out_buf, double g_dep, double inv_g_dep, const int8_t *rot,
@@ -59,6 +62,7 @@ struct AntsHandle {
     hipEvent_t ev[ANTSRL_TIMING_EVENTS]; // measurement hook (antsrl_set_timing_events)
     bool ev_armed;
     uint32_t obs_seq;      // cell-meta path: observations since the explored stamps were last re-based
+    PolArgs pol;           // in-loop policy (antsrl_set_inloop_policy); pol.pack == NULL: none
     // Deferred update (include/antsrl.h): Environment.update was requested, its host-side bookkeeping is done, its
     // kernel has NOT been enqueued yet — the next antsrl_step runs it fused with the move (k_update_move); every other
     // entry point that touches the state enqueues it first (flush_pending).
@@ -198,6 +202,7 @@ static size_t carve(const AntsCfg *c, DState *s, unsigned char *base)
     d.reward_primed = (uint8_t *)take(E);
     d.gen_discs = (int32_t *)take(4 * E * ANTSRL_MAX_FOOD_DISCS * 3);
     d.gen_perlin = (int32_t *)take(4 * E * 2);
+    d.pol_pack = (unsigned char *)take(ANTSRL_POL_PACK_BYTES);
     if (s) *s = d;
     return off;
 }
@@ -318,6 +323,7 @@ extern "C" int antsrl_create(const AntsCfg *cfg, void *workspace, size_t workspa
     fill_kp(cfg, &h->p);
     carve(cfg, &h->p.s, (unsigned char *)workspace);
     h->cur = 0; h->steps_since_update = 0; h->need_full_collect = true; h->is_reset = false; h->pend_update = false;
+    h->pol = PolArgs{};
     h->sweeps = 0; h->need_wall_clear = false;
     h->has_gen = false; h->episode_seed = 0; h->host_timestep = 1; h->obs_bf16 = false;
     h->ws_bytes = need;
@@ -411,6 +417,7 @@ extern "C" int antsrl_set_obs_format(AntsHandle *h, int format)
     if (!h) return fail(ANTSRL_E_INVALID, "NULL handle");
     if (format != ANTSRL_OBS_F32 && format != ANTSRL_OBS_BF16) return fail(ANTSRL_E_INVALID, "bad observation format %d", format);
     h->obs_bf16 = format == ANTSRL_OBS_BF16;
+    if (!h->obs_bf16) h->pol = PolArgs{}; // (the in-loop policy reads bfloat16 rows)
     return ANTSRL_OK;
 }
 
@@ -451,7 +458,7 @@ static int meta_observe(AntsHandle *h, const int8_t *rot, const int8_t *ph, floa
     if (timed) (void)hipEventRecord(h->ev[2], st);
     e = antsrl_launch_perceive(h->p, h->cur, obs, agent_state, reward,
                                (stepping ? ACT_STEP : 0) | (obs ? ACT_HAS_OBS : 0) | (obs && h->obs_bf16 ? ACT_OBS_BF16 : 0),
-                               h->obs_seq, st);
+                               h->obs_seq, st, &h->pol);
     if (e != hipSuccess) return hip_fail(e, "perceive");
     return ANTSRL_OK;
 }
@@ -672,6 +679,33 @@ extern "C" int antsrl_policy_mlp(AntsHandle *h, const float *obs, const float *a
     hipError_t e = antsrl_launch_policy(obs, agent_state, w1, b1, w2, b2, w3, b3, rotation, pheromone, logits,
                                         (int)n_ants, n_features, (hipStream_t)stream, h && h->obs_bf16);
     if (e != hipSuccess) return hip_fail(e, "policy_mlp");
+    return ANTSRL_OK;
+}
+
+extern "C" int antsrl_set_inloop_policy(AntsHandle *h, int32_t n_features, const float *w1, const float *b1, const float *w2,
+                                        const float *b2, const float *w3, const float *b3, int8_t *rotation_next,
+                                        int8_t *pheromone_next, void *stream)
+{
+    if (!h) return fail(ANTSRL_E_INVALID, "NULL handle");
+    if (!w1) { // switch it off
+        h->pol = PolArgs{};
+        return ANTSRL_OK;
+    }
+    if (!b1 || !w2 || !b2 || !rotation_next)
+        return fail(ANTSRL_E_INVALID, "inloop_policy: w1, b1, w2, b2, rotation_next are required");
+    if ((w3 == nullptr) != (b3 == nullptr) || (pheromone_next && !w3))
+        return fail(ANTSRL_E_INVALID, "inloop_policy: w3/b3 go together and are needed for a pheromone output");
+    if (n_features != h->p.PP * h->p.K)
+        return fail(ANTSRL_E_INVALID, "inloop_policy: n_features must be P*P*K = %d", h->p.PP * h->p.K);
+    if (!h->obs_bf16 || !antsrl_inloop_policy_supported(h->p))
+        return fail(ANTSRL_E_UNSUPPORTED, "inloop_policy needs the cell-meta path (ANTSRL_Q_CELL_META) with bfloat16 "
+                                          "observations (antsrl_set_obs_format) — use antsrl_policy_mlp otherwise");
+    hipError_t e = antsrl_launch_policy_pack(h->p.s.pol_pack, w1, b1, w2, b2, w3, b3, n_features, (hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail(e, "inloop_policy pack");
+    h->pol.pack = h->p.s.pol_pack;
+    h->pol.rot = rotation_next;
+    h->pol.ph = pheromone_next;
+    h->pol.ks = (n_features + 15) / 16;
     return ANTSRL_OK;
 }
 

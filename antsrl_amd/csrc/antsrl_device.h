@@ -81,10 +81,25 @@ struct DState {
                                              //        environment's Python stream by k_gen_mt)
     // cell-meta layout only (KP::meta)
     uint8_t *primed_cur;                     // [E]   reward_primed as the current observation must see it
+    unsigned char *pol_pack;                 // ANTSRL_POL_PACK_BYTES: the in-loop policy's weights as MFMA fragments (antsrl_policy.hip)
 };
 
 // Kernel parameter block, passed by value (lives in the kernarg segment; every field is
 // wave-uniform so the compiler reads it with scalar loads).
+// In-loop policy (antsrl_set_inloop_policy): the reference's linear DQN net evaluated by k_perceive on the rows it has just
+// written (bf16), per 32-ant tile.  All pointers device memory; the packs live in DState::pol_pack (k_policy_pack).
+#define ANTSRL_POL_MAX_KSTEPS 64
+#define ANTSRL_POL_WPACK_BYTES (ANTSRL_POL_MAX_KSTEPS * 64 * 16)      // [ks][64 lanes] bf16x8: W1's A fragments
+#define ANTSRL_POL_A2PACK_BYTES (2 * 64 * 16)                          // [2][64 lanes] bf16x8: the heads' A fragments
+#define ANTSRL_POL_LANEPACK_FLOATS (48 * 64 + 8)                       // bias1 / was0 / was1 [16][64] each, then hb[6]
+#define ANTSRL_POL_PACK_BYTES (ANTSRL_POL_WPACK_BYTES + ANTSRL_POL_A2PACK_BYTES + 4 * ANTSRL_POL_LANEPACK_FLOATS)
+struct PolArgs {
+    const unsigned char *pack; // DState::pol_pack, or NULL: no in-loop policy
+    int8_t *rot, *ph;          // [E][N] next actions (ph may be NULL)
+    int ks;                    // ceil(F / 16)
+    int _pad;
+};
+
 struct KP {
     DState s;
     int32_t E, N, W, H, C, R, K, P, PP, r, words;

@@ -206,7 +206,7 @@ struct PrcOff {
     size_t total;
 };
 
-__host__ __device__ __forceinline__ PrcOff prc_offsets(int run, int PP, int K, int R, int nwaves)
+__host__ __device__ __forceinline__ PrcOff prc_offsets(int run, int PP, int K, int R, int nwaves, bool no_stage = false)
 {
     PrcOff o;
     o.rock = 0;
@@ -216,24 +216,109 @@ __host__ __device__ __forceinline__ PrcOff prc_offsets(int run, int PP, int K, i
     o.stage = (uint32_t)align_up(o.rm + 4 * (size_t)run, 16);
     const size_t rowf = (size_t)PP * K;
     o.stride = (uint32_t)((2 * rowf + 32 + 3) / 4 * 4); // floats: misalignment / carry (< one 128-byte line) + two rows
-    o.per_wave = (uint32_t)align_up(o.stage + 4 * (size_t)o.stride, 16);
+    o.per_wave = (uint32_t)align_up(o.stage + (no_stage ? 0 : 4 * (size_t)o.stride), 16); // (POLICY: the tile image is the staging)
     o.total = o.wave0 + (size_t)nwaves * o.per_wave;
     return o;
 }
+
+// POLICY: bf16 elements of the workgroup's tile image: up to 7 elements of alignment shift, 32 rows, and what the last
+// k-step's 5-dword read can reach past them
+__host__ __device__ __forceinline__ uint32_t prc_policy_img_elems(int row) { return (uint32_t)((32 * row + 8 + 32 + 7) / 8 * 8); }
 
 #ifndef PRC_TPB
 #define PRC_TPB 256 // 4 waves per workgroup; 64 / 128 measured no better (profiles/r02/prc_tpb.txt)
 #endif
 
+// ---------------------------------------------------------------------------------------------------
+// In-loop policy (antsrl_set_inloop_policy, BASELINE config 5): the reference's linear DQN net (antsrl_policy.hip) on the 32
+// rows a workgroup has just written, straight from its LDS image of them — the standalone kernel re-reads the whole
+// observation tensor from HBM for the same arithmetic.  The consumer of k_policy_flat verbatim (same fragments, same order
+// of MFMAs and additions: the actions are bit-identical to antsrl_policy_mlp on the stored rows); W1's A fragments come from
+// the pre-packed, L2-resident DState::pol_pack (k_policy_pack) instead of a per-workgroup LDS copy.
+// ---------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(8))) __bf16 prc_bf16x8;
+typedef __attribute__((ext_vector_type(16))) float prc_f32x16;
+typedef __attribute__((ext_vector_type(4))) uint32_t prc_u4;
+
+__device__ __forceinline__ void policy_tile(const PolArgs &pol, const uint16_t *img, const uint32_t img_shift, const float *as_lds,
+                                            const int F, const int rows, const size_t ant0, const int lane)
+{
+    const int r = lane & 31, h = lane >> 5;
+    const prc_u4 *wpack = reinterpret_cast<const prc_u4 *>(pol.pack);
+    const prc_u4 *a2pack = reinterpret_cast<const prc_u4 *>(pol.pack + ANTSRL_POL_WPACK_BYTES);
+    const float *lanepack = reinterpret_cast<const float *>(pol.pack + ANTSRL_POL_WPACK_BYTES + ANTSRL_POL_A2PACK_BYTES);
+    const int rc = min(r, rows - 1);
+    const float as0 = (float)(__bf16)as_lds[2 * rc], as1 = (float)(__bf16)as_lds[2 * rc + 1];
+    prc_f32x16 acc;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) acc[g] = 0.0f;
+    const uint32_t off0 = img_shift + (uint32_t)r * (uint32_t)F + 8u * h; // (element offset from the 16-byte aligned image base)
+    const int ks = pol.ks;
+    // W1's fragments stream from L2 POL_AHEAD k-steps ahead of the MFMA that takes them (the chain is the workgroup's
+    // tail: its other waves are done, so the L2 round trips are not hidden by anything else)
+    constexpr int POL_AHEAD = 6;
+    prc_u4 a[POL_AHEAD];
+#pragma unroll
+    for (int i = 0; i < POL_AHEAD; ++i) a[i] = wpack[min(i, ks - 1) * 64 + lane];
+    for (int s0 = 0; s0 < ks; s0 += POL_AHEAD) {
+#pragma unroll
+        for (int i = 0; i < POL_AHEAD; ++i) {
+            const int s = s0 + i;
+            const prc_u4 a_s = a[i];
+            a[i] = wpack[min(s + POL_AHEAD, ks - 1) * 64 + lane];
+            if (s < ks) {
+                const uint32_t off = off0 + 16u * s, sh = (off & 1u) * 16u;
+                const uint32_t *d = reinterpret_cast<const uint32_t *>(img) + (off >> 1);
+                const uint32_t d0 = d[0], d1 = d[1], d2 = d[2], d3 = d[3], d4 = d[4];
+                const prc_u4 packed = {__builtin_amdgcn_alignbit(d1, d0, sh), __builtin_amdgcn_alignbit(d2, d1, sh),
+                                       __builtin_amdgcn_alignbit(d3, d2, sh), __builtin_amdgcn_alignbit(d4, d3, sh)};
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(prc_bf16x8, a_s),
+                                                              __builtin_bit_cast(prc_bf16x8, packed), acc, 0, 0, 0);
+            }
+        }
+    }
+    prc_f32x16 acc2;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) acc2[g] = 0.0f;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        prc_bf16x8 hfrag;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int g = 8 * s + j;
+            const float bias1 = lanepack[g * 64 + lane], was0 = lanepack[(16 + g) * 64 + lane], was1 = lanepack[(32 + g) * 64 + lane];
+            hfrag[j] = (__bf16)(acc[g] + (as0 * was0 + as1 * was1) + bias1);
+        }
+        acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(prc_bf16x8, a2pack[s * 64 + lane]), hfrag, acc2, 0, 0, 0);
+    }
+    float lg[6];
+    lg[0] = acc2[0]; lg[1] = acc2[1]; lg[2] = acc2[2]; lg[3] = acc2[3];
+    lg[4] = __shfl(acc2[0], r + 32); lg[5] = __shfl(acc2[1], r + 32);
+#pragma unroll
+    for (int o = 0; o < 6; ++o) lg[o] += lanepack[48 * 64 + o];
+    if (h == 0 && r < rows) {
+        int ar = 0, ap = 0; // torch.max(...).indices: first maximum wins
+        if (lg[1] > lg[ar]) ar = 1;
+        if (lg[2] > lg[ar]) ar = 2;
+        if (lg[4] > lg[3 + ap]) ap = 1;
+        if (lg[5] > lg[3 + ap]) ap = 2;
+        pol.rot[ant0 + r] = (int8_t)(ar - 1);
+        if (pol.ph) pol.ph[ant0 + r] = (int8_t)ap;
+    }
+}
+
 // HAS_OBS is a template parameter on purpose: with the observation stores behind a run-time branch the
 // compiler cannot count them, every wait on a gather becomes vmcnt(0), i.e. a wait for the previous
 // group's observation stores to be acknowledged by memory — stores and everything else then add up instead
 // of overlapping (measured: 0.245 ms against 0.092 ms without the stores).
-template <int LAYOUT, bool OBS16, bool ILV, bool HAS_OBS>
+// POLICY (with OBS16 and HAS_OBS only): the workgroup also keeps the bf16 rows of its ants as one contiguous LDS image and
+// its first wave evaluates the in-loop policy on them at the end (policy_tile).
+template <int LAYOUT, bool OBS16, bool ILV, bool HAS_OBS, bool POLICY = false>
 __global__ void __launch_bounds__(PRC_TPB, 4)
 k_perceive(const KP p, const float *__restrict__ cells, float *__restrict__ obs, float *__restrict__ agent_state,
-           float *__restrict__ reward, const int flags, const uint32_t seq, const int run, const int nseg)
+           float *__restrict__ reward, const int flags, const uint32_t seq, const int run, const int nseg, const PolArgs pol)
 {
+    static_assert(!POLICY || (OBS16 && HAS_OBS), "the in-loop policy reads the bfloat16 rows the kernel writes");
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr int C = 2;
     const int tid = threadIdx.x;
@@ -256,12 +341,26 @@ k_perceive(const KP p, const float *__restrict__ cells, float *__restrict__ obs,
             seg = b % nseg;
         }
     }
-    const PrcOff lo = prc_offsets(run, PP, K, R, nwaves);
+    const PrcOff lo = prc_offsets(run, PP, K, R, nwaves, POLICY);
     double *rock = (double *)(smem + lo.rock);
     unsigned char *wbase = smem + lo.wave0 + (size_t)wave * lo.per_wave;
     AntFrame *frames = (AntFrame *)(wbase + lo.frame);
     uint32_t *rmask = (uint32_t *)(wbase + lo.rm);
     float *stage = (float *)(wbase + lo.stage);
+    // POLICY: [tile rows][row] bf16, contiguous like the rows in memory (+ a zeroed pad the last k-step reads into), then
+    // {holding, seed} of the tile's ants
+    uint16_t *pol_img = reinterpret_cast<uint16_t *>(smem + align_up(lo.total, 16));
+    float *pol_as = reinterpret_cast<float *>(pol_img + prc_policy_img_elems(PP * K));
+    if constexpr (POLICY) {
+        for (uint32_t i = tid; i < prc_policy_img_elems(PP * K) / 8; i += PRC_TPB)
+            reinterpret_cast<uint4 *>(pol_img)[i] = make_uint4(0, 0, 0, 0); // rows of ants past the env's end stay zero
+    }
+    // The image doubles as the copy-out staging of all four waves: it starts at the tile's own 16-byte misalignment in
+    // the observation tensor, so LDS and global addresses of every row agree modulo 16 bytes (no per-wave staging rows:
+    // a third less LDS per workgroup, one LDS write per value).
+    const size_t tile_elem0 = ((size_t)e * N + (size_t)(seg * nwaves * run)) * (size_t)(PP * K);
+    uint16_t *tile0 = pol_img + (uint32_t)((((uintptr_t)obs >> 1) + tile_elem0) & 7);
+    (void)tile0;
 
     const size_t eN = (size_t)e * N;
     const int i_begin = min((seg * nwaves + wave) * run, N), i_end = min(i_begin + run, N);
@@ -307,7 +406,10 @@ k_perceive(const KP p, const float *__restrict__ cells, float *__restrict__ obs,
         rmask[lane] = rm;
     }
     wave_lds_sync();
-    if (n_run <= 0) return; // (no barrier below: waves run independently from here on)
+    if (n_run <= 0) { // (no barrier below: waves run independently from here on — but for the policy's hand-over)
+        if constexpr (POLICY) __syncthreads();
+        return;
+    }
 
     const float *ph = cells + (size_t)e * G * (size_t)p.ps;
     const float *fm = p.s.food + (size_t)e * G * p.fs; // {food, META} records when not interleaved
@@ -478,7 +580,10 @@ k_perceive(const KP p, const float *__restrict__ cells, float *__restrict__ obs,
                     asm volatile("" ::"v"(v_ants), "v"(pvs[0]), "v"(pvs[1]), "v"(v_area), "v"(v_wall), "v"(c_fd[u]), "v"(v_rock));
                 } else if (OBS16) {
                     // bfloat16 observations: the same staging and copy-out on 2-byte elements (8 per 16 bytes)
-                    uint16_t *o16 = reinterpret_cast<uint16_t *>(stage) + carry + (uint32_t)u * row + qK;
+                    // (POLICY: straight into the workgroup's tile image, row = the ant's index in the tile; a clamped
+                    // duplicate of the run's last ant has no row of its own)
+                    uint16_t *o16 = POLICY ? tile0 + (uint32_t)(wave * run + min(j0 + u, n_run - 1)) * row + qK
+                                           : reinterpret_cast<uint16_t *>(stage) + carry + (uint32_t)u * row + qK;
                     o16[0] = bf16_bits(m ? v_ants : -1.0f); o16[1] = bf16_bits(m ? pvs[0] : -1.0f);
                     o16[2] = bf16_bits(m ? pvs[1] : -1.0f); o16[3] = bf16_bits(m ? v_area : -1.0f);
                     o16[4] = bf16_bits(m ? v_wall : -1.0f); o16[5] = bf16_bits(m ? c_fd[u] : -1.0f);
@@ -504,7 +609,9 @@ k_perceive(const KP p, const float *__restrict__ cells, float *__restrict__ obs,
             if (OBS16) {
                 uint16_t *dst16 = reinterpret_cast<uint16_t *>(obs) + ((size_t)e * N + (size_t)(i_begin + j0)) * row;
                 const uint32_t mis16 = (uint32_t)(((uintptr_t)dst16 >> 1) & 7);
-                uint16_t *st16 = reinterpret_cast<uint16_t *>(stage), *d_al = dst16 - mis16;
+                uint16_t *d_al = dst16 - mis16;
+                // POLICY: the rows sit in the tile image at the same 16-byte phase as in memory
+                uint16_t *st16 = POLICY ? tile0 + (uint32_t)(wave * run + j0) * row - mis16 : reinterpret_cast<uint16_t *>(stage);
                 const FlushPlanB16 f = flush_plan_b16((uint32_t)lane, mis16, rowp, (uint32_t)((uintptr_t)d_al >> 4) & 7u);
                 const uint4 w1 = reinterpret_cast<const uint4 *>(st16)[f.g1];
                 const uint4 w2 = reinterpret_cast<const uint4 *>(st16)[f.g2];
@@ -623,6 +730,10 @@ k_perceive(const KP p, const float *__restrict__ cells, float *__restrict__ obs,
             store_stream(agent_state + a * 2 + 0, hold);
             store_stream(agent_state + a * 2 + 1, p.s.seed[a]);
         }
+        if constexpr (POLICY) { // the net's two agent_state inputs (RL_api.py:160-162)
+            pol_as[2 * (wave * run + lane)] = hold;
+            pol_as[2 * (wave * run + lane) + 1] = p.s.seed[a];
+        }
         double rw = 0.0;
         if (p.reward_kind != ANTSRL_REWARD_NONE) {
             const float prev_h = p.s.primed_cur[e] ? p.s.prev_holding[a] : hold;
@@ -651,6 +762,12 @@ k_perceive(const KP p, const float *__restrict__ cells, float *__restrict__ obs,
         }
         if (reward) store_stream(reward + a, (float)rw);
         if ((flags & ACT_STEP) && rw - p.reward_threshold > 0) p.s.reward_state[a] = 255; // ants.py:119-121
+    }
+    if constexpr (POLICY) {
+        __syncthreads(); // every wave's rows and agent_state inputs are in the image
+        const int t0 = seg * nwaves * run; // first ant of this workgroup's tile
+        if (wave == 0)
+            policy_tile(pol, pol_img, (uint32_t)(tile0 - pol_img), pol_as, (int)row, min(nwaves * run, N - t0), eN + (size_t)t0, lane);
     }
 }
 
@@ -759,29 +876,38 @@ hipError_t antsrl_launch_update_move(const KP &p, int out_buf, double g_dep, dou
     return hipGetLastError();
 }
 
-template <int LAYOUT, bool OBS16, bool ILV, bool HAS_OBS>
+template <int LAYOUT, bool OBS16, bool ILV, bool HAS_OBS, bool POLICY = false>
 static hipError_t launch_perceive_t(const KP &p, const float *cells, float *obs, float *agent_state, float *reward,
-                                    int flags, uint32_t seq, hipStream_t st)
+                                    int flags, uint32_t seq, hipStream_t st, const PolArgs &pol = PolArgs{})
 {
     const int run = pick_run(p), nwaves = PRC_TPB / 64;
     if (run < 1 || run > 64) return hipErrorInvalidValue;
+    if (POLICY && run * nwaves > 32) return hipErrorInvalidValue; // one MFMA tile of 32 ants per workgroup
     const int nseg = (p.N + run * nwaves - 1) / (run * nwaves);
-    const PrcOff lo = prc_offsets(run, p.PP, p.K, p.R, nwaves);
+    const PrcOff lo = prc_offsets(run, p.PP, p.K, p.R, nwaves, POLICY);
     const size_t pad = PROF_ENV("ANTSRL_PRC_LDS_PAD") ? (size_t)atoi(PROF_ENV("ANTSRL_PRC_LDS_PAD")) * 1024 : 0; // occupancy knob
-    hipLaunchKernelGGL((k_perceive<LAYOUT, OBS16, ILV, HAS_OBS>), dim3((unsigned)((size_t)p.E * nseg)), dim3(PRC_TPB), lo.total + pad, st, p,
-                       cells, obs, agent_state, reward, flags, seq, run, nseg);
+    size_t lds = lo.total + pad;
+    if (POLICY) lds = align_up(lo.total, 16) + 2 * (size_t)prc_policy_img_elems(p.PP * p.K) + 4 * 64 + pad;
+    if (lds > 64 * 1024) return hipErrorInvalidValue; // (never with the shapes antsrl_meta_supported admits)
+    hipLaunchKernelGGL((k_perceive<LAYOUT, OBS16, ILV, HAS_OBS, POLICY>), dim3((unsigned)((size_t)p.E * nseg)), dim3(PRC_TPB), lds, st, p,
+                       cells, obs, agent_state, reward, flags, seq, run, nseg, pol);
     return hipGetLastError();
 }
 
+// the in-loop policy needs one tile of at most 32 ants per k_perceive workgroup
+bool antsrl_inloop_policy_supported(const KP &p) { return p.meta && pick_run(p) * (PRC_TPB / 64) <= 32; }
+
 hipError_t antsrl_launch_perceive(const KP &p, int cur, float *obs, float *agent_state, float *reward, int flags,
-                                  uint32_t seq, hipStream_t st)
+                                  uint32_t seq, hipStream_t st, const PolArgs *pol)
 {
     const int layout = prc_layout(p);
     const bool o16 = (flags & ACT_OBS_BF16) != 0, ilv = p.ps == 4 && p.fs == 4;
     const float *cells = p.s.phero[cur];
+    const bool with_pol = pol && pol->pack && obs && o16; // (the in-loop policy reads the bf16 rows: antsrl_set_inloop_policy)
 #define PRC_GO(LY)                                                                                             \
     {                                                                                                          \
         if (!obs) return launch_perceive_t<LY, false, ILVV, false>(p, cells, obs, agent_state, reward, flags, seq, st); \
+        if (with_pol) return launch_perceive_t<LY, true, ILVV, true, true>(p, cells, obs, agent_state, reward, flags, seq, st, *pol); \
         if (o16) return launch_perceive_t<LY, true, ILVV, true>(p, cells, obs, agent_state, reward, flags, seq, st);    \
         return launch_perceive_t<LY, false, ILVV, true>(p, cells, obs, agent_state, reward, flags, seq, st);            \
     }

@@ -49,7 +49,7 @@ k_policy_mlp(const float *__restrict__ obs, const float *__restrict__ agent_stat
              const float *__restrict__ b1, const float *__restrict__ w2, const float *__restrict__ b2,
              const float *__restrict__ w3, const float *__restrict__ b3, int8_t *__restrict__ rot_out,
              int8_t *__restrict__ ph_out, float *__restrict__ logits_out, const int M, const int F,
-             const int ksteps)
+             const int ksteps, const int newest_first)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     __bf16 *w1s = reinterpret_cast<__bf16 *>(smem); // [32][KP], KP = 16*ksteps + 8 (8 = bank skew)
@@ -107,7 +107,10 @@ k_policy_mlp(const float *__restrict__ obs, const float *__restrict__ agent_stat
     __bf16 *stg = w1s + POL_HIDDEN * KP + (size_t)wib * 32 * POL_SROW; // [32][POL_SROW]
     const int la = lane >> 4, lf = lane & 15;                          // loader role: ant la + 4 i, floats 4 lf .. 4 lf + 3
     const int nchunks = (IN + POL_KC - 1) / POL_KC;
-    for (int t = wave; t < ntiles; t += nwaves) {
+    for (int t0 = wave; t0 < ntiles; t0 += nwaves) {
+        // LAST tile first: the rows k_perceive wrote most recently are the ones still in the 256 MiB Infinity Cache; in
+        // forward order every row's reuse distance is the whole tensor plus the gathers (an LRU's worst case)
+        const int t = newest_first ? ntiles - 1 - t0 : t0;
         const int ant = min(t * 32 + r, M - 1); // clamped: duplicates are not written back
         const int rows = min(32, M - t * 32);
         const float *tile = obs + (size_t)t * 32 * F;
@@ -300,7 +303,8 @@ k_policy_flat(const float *__restrict__ obs, const float *__restrict__ agent_sta
               const float *__restrict__ b1, const float *__restrict__ w2, const float *__restrict__ b2,
               const float *__restrict__ w3, const float *__restrict__ b3, int8_t *__restrict__ rot_out,
               int8_t *__restrict__ ph_out, float *__restrict__ logits_out, const int M, const int F,
-              const int ksteps /* ceil(F / 16) */, const int tile_elems /* LDS image size per wave, bf16 */)
+              const int ksteps /* ceil(F / 16) */, const int tile_elems /* LDS image size per wave, bf16 */,
+              const int newest_first)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     __bf16 *w1s = reinterpret_cast<__bf16 *>(smem); // [32][KP], KP = 16*ksteps + 8 (8 = bank skew)
@@ -342,7 +346,10 @@ k_policy_flat(const float *__restrict__ obs, const float *__restrict__ agent_sta
 
     const int ntiles = (M + 31) / 32;
     const __bf16 *wrow = w1s + r * KP + 8 * h;
-    for (int t = wave; t < ntiles; t += nwaves) {
+    for (int t0 = wave; t0 < ntiles; t0 += nwaves) {
+        // LAST tile first: the rows k_perceive wrote most recently are the ones still in the 256 MiB Infinity Cache; in
+        // forward order every row's reuse distance is the whole tensor plus the gathers (an LRU's worst case)
+        const int t = newest_first ? ntiles - 1 - t0 : t0;
         const int ant = min(t * 32 + r, M - 1); // clamped: duplicates are not written back
         const int rows = min(32, M - t * 32);
         const uint32_t nelem = (uint32_t)rows * (uint32_t)F;
@@ -427,10 +434,68 @@ k_policy_flat(const float *__restrict__ obs, const float *__restrict__ agent_sta
     }
 }
 
+// ===================================================================================
+// k_policy_pack — the weights as k_perceive's in-loop policy takes them (policy_tile, antsrl_perceive.hip): W1's
+// observation columns as bf16 MFMA A fragments per (k-step, lane), the heads' A fragments, and the per-lane fp32 terms
+// (bias1, the bf16-rounded weights of the two agent_state inputs, the head biases) — exactly what k_policy_flat's
+// prologue builds per workgroup, built once per antsrl_set_inloop_policy.
+// ===================================================================================
+__global__ void __launch_bounds__(64)
+k_policy_pack(unsigned char *__restrict__ pack, const float *__restrict__ w1, const float *__restrict__ b1,
+              const float *__restrict__ w2, const float *__restrict__ b2, const float *__restrict__ w3,
+              const float *__restrict__ b3, const int F, const int ksteps)
+{
+    const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+    const int IN = F + 2;
+    bf16x8 *wpack = reinterpret_cast<bf16x8 *>(pack);
+    bf16x8 *a2pack = reinterpret_cast<bf16x8 *>(pack + ANTSRL_POL_WPACK_BYTES);
+    float *lanepack = reinterpret_cast<float *>(pack + ANTSRL_POL_WPACK_BYTES + ANTSRL_POL_A2PACK_BYTES);
+    for (int s = 0; s < ksteps; ++s) {
+        bf16x8 a;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = 16 * s + 8 * h + j;
+            a[j] = (__bf16)(k < F ? w1[(size_t)r * IN + k] : 0.0f);
+        }
+        wpack[s * 64 + lane] = a;
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        bf16x8 a;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int hid = 16 * s + 8 * (j >> 2) + 4 * h + (j & 3);
+            const float wa = w2[min(r, 2) * POL_HIDDEN + hid];
+            const float wb = w3 ? w3[min(max(r - 3, 0), 2) * POL_HIDDEN + hid] : 0.0f;
+            a[j] = (__bf16)(r < 3 ? wa : (r < 6 ? wb : 0.0f));
+        }
+        a2pack[s * 64 + lane] = a;
+    }
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+        const int hid = (g & 3) + 8 * (g >> 2) + 4 * h;
+        lanepack[g * 64 + lane] = b1[hid];
+        lanepack[(16 + g) * 64 + lane] = (float)(__bf16)w1[(size_t)hid * IN + F];
+        lanepack[(32 + g) * 64 + lane] = (float)(__bf16)w1[(size_t)hid * IN + F + 1];
+    }
+    if (lane < 6) lanepack[48 * 64 + lane] = lane < 3 ? b2[lane] : (w3 ? b3[lane - 3] : 0.0f);
+}
+
+hipError_t antsrl_launch_policy_pack(unsigned char *pack, const float *w1, const float *b1, const float *w2, const float *b2,
+                                     const float *w3, const float *b3, int F, hipStream_t st)
+{
+    const int ks = (F + 15) / 16;
+    if (ks > ANTSRL_POL_MAX_KSTEPS) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_policy_pack, dim3(1), dim3(64), 0, st, pack, w1, b1, w2, b2, w3, b3, F, ks);
+    return hipGetLastError();
+}
+
 hipError_t antsrl_launch_policy(const float *obs, const float *agent_state, const float *w1, const float *b1,
                                 const float *w2, const float *b2, const float *w3, const float *b3, int8_t *rot,
                                 int8_t *ph, float *logits, int M, int F, hipStream_t st, bool obs_bf16)
 {
+    const int newest_first = PROF_ENV("ANTSRL_POLICY_OLDEST_FIRST") ? 0 : 1; // tile order, see the kernels
+
     if (M < 1 || F < 1) return hipErrorInvalidValue;
     {
         // flat-stream form: W1 (observation columns) + two wave-private tile images (32 F elements + the
@@ -452,13 +517,13 @@ hipError_t antsrl_launch_policy(const float *obs, const float *agent_state, cons
                 if (lds > attr[dev]) { e = hipFuncSetAttribute((const void *)k_policy_flat<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr[dev] = lds; }
                 if (e != hipSuccess) return e;
                 hipLaunchKernelGGL(k_policy_flat<true>, dim3(blocks), dim3(128), lds, st, obs, agent_state, w1, b1, w2, b2, w3,
-                                   b3, rot, ph, logits, M, F, ks, tile_elems);
+                                   b3, rot, ph, logits, M, F, ks, tile_elems, newest_first);
             } else {
                 static size_t attr[ANTSRL_MAX_DEVICES] = {}; // per kernel function and per device
                 if (lds > attr[dev]) { e = hipFuncSetAttribute((const void *)k_policy_flat<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr[dev] = lds; }
                 if (e != hipSuccess) return e;
                 hipLaunchKernelGGL(k_policy_flat<false>, dim3(blocks), dim3(128), lds, st, obs, agent_state, w1, b1, w2, b2, w3,
-                                   b3, rot, ph, logits, M, F, ks, tile_elems);
+                                   b3, rot, ph, logits, M, F, ks, tile_elems, newest_first);
             }
             return hipGetLastError();
         }
@@ -482,7 +547,7 @@ hipError_t antsrl_launch_policy(const float *obs, const float *agent_state, cons
             attr[dev] = lds;
         }
         hipLaunchKernelGGL(k_policy_mlp<true>, dim3(blocks), dim3(256), lds, st, obs, agent_state, w1, b1, w2, b2, w3, b3,
-                           rot, ph, logits, M, F, ksteps);
+                           rot, ph, logits, M, F, ksteps, newest_first);
     } else {
         static size_t attr[ANTSRL_MAX_DEVICES] = {};
         if (lds > attr[dev]) {
@@ -491,7 +556,7 @@ hipError_t antsrl_launch_policy(const float *obs, const float *agent_state, cons
             attr[dev] = lds;
         }
         hipLaunchKernelGGL(k_policy_mlp<false>, dim3(blocks), dim3(256), lds, st, obs, agent_state, w1, b1, w2, b2, w3, b3,
-                           rot, ph, logits, M, F, ksteps);
+                           rot, ph, logits, M, F, ksteps, newest_first);
     }
     return hipGetLastError();
 }

@@ -81,6 +81,29 @@ class LinearPolicy:
         rot = self._rot.view(lead)
         return rot, (self._ph.view(lead) if self._ph is not None else None)
 
+    def attach(self, env) -> None:
+        """In-loop form (antsrl_set_inloop_policy): from now on every observation `env` writes also leaves the net's
+        actions for the NEXT step in `env.next_rotation` / `env.next_pheromone` (int8 [E, N]) — the values act() returns
+        for that observation, computed inside the observation kernel.  Needs bfloat16 observations on the cell-meta
+        path; detach() switches it off."""
+        assert env.obs.dtype == torch.bfloat16, "the in-loop policy reads bfloat16 observation rows"
+        E, N = env.cfg.n_envs, env.cfg.n_ants
+        env.next_rotation = torch.zeros((E, N), dtype=torch.int8, device=self.device)
+        env.next_pheromone = torch.zeros((E, N), dtype=torch.int8, device=self.device) if self.w3 is not None else None
+
+        def p(t):
+            return None if t is None else C.c_void_p(t.data_ptr())
+
+        with torch.cuda.device(self.device):
+            st = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+            _lib.check(self._lib.antsrl_set_inloop_policy(env._h, self.n_features, p(self.w1), p(self.b1), p(self.w2), p(self.b2),
+                                                          p(self.w3), p(self.b3), p(env.next_rotation), p(env.next_pheromone), st),
+                       "set_inloop_policy")
+
+    def detach(self, env) -> None:
+        _lib.check(self._lib.antsrl_set_inloop_policy(env._h, self.n_features, None, None, None, None, None, None, None, None, None),
+                   "set_inloop_policy")
+
     def reference_logits(self, obs: torch.Tensor, agent_state: torch.Tensor) -> torch.Tensor:
         """The same network in plain PyTorch fp32 on bf16-rounded operands (test comparator)."""
         x = torch.cat([obs.reshape(-1, self.n_features), agent_state.reshape(-1, 2)], dim=1)

@@ -191,6 +191,9 @@ def main():
                     help="skip the short extra run with the per-step sweep kernel forced (explicit_sweep record)")
     ap.add_argument("--policy", default=None, choices=["random", "mlp"],
                     help="mlp: the reference's linear DQN net evaluated in-loop on the GPU (bf16 MFMA)")
+    ap.add_argument("--policy-kernel", default="inloop", choices=["inloop", "separate"],
+                    help="--policy mlp: the net inside the observation kernel (antsrl_set_inloop_policy; needs bf16 observations) "
+                         "or as its own kernel over the observation tensor (antsrl_policy_mlp) — for A/B runs on one box")
     ap.add_argument("--obs-dtype", default=None, choices=["f32", "bf16"],
                     help="observation tensor format (default: f32; c5, whose bf16 policy rounds its input anyway: bf16)")
     ap.add_argument("--explicit-sweep", action="store_true",
@@ -255,17 +258,22 @@ def main():
         from antsrl_amd.dist import RewardGather
         gather = RewardGather(world * E, cfg.n_ants, dev)
 
-    policy = None
+    policy, inloop = None, False
     if policy_kind == "mlp":
         from antsrl_amd.policy import LinearPolicy
         policy = LinearPolicy(cfg.pside * cfg.pside * cfg.n_channels, dev, seed=5 + rank)
+        inloop = args.policy_kernel == "inloop" and obs_dtype == "bf16" and bool(env.query(cm.Q_CELL_META))
+        if inloop:
+            policy.attach(env)  # every observation now also leaves the next actions in env.next_rotation / next_pheromone
         env.observe()  # main.py:88: first observation feeds the first action
 
     from antsrl_amd.dist import ShardedStepper
     stepper = ShardedStepper(env, gather, args.gather)  # the N > 1 sequence: tests/test_dist_cpu.py runs the same code
 
     def device_step(t):
-        if policy is not None:  # agent.get_action on the device, then api.step + env.update
+        if policy is not None and inloop:  # the actions were computed by the previous observation kernel
+            env.step_update(env.next_rotation, env.next_pheromone, None)
+        elif policy is not None:  # agent.get_action on the device, then api.step + env.update
             a_rot, a_ph = policy.act(env.obs, env.agent_state, env=env)
             env.step_update(a_rot, a_ph, None)
         else:
@@ -394,7 +402,9 @@ def main():
                                    "(cell-meta layout, %d ants per wave)" % env.query(cm.Q_PERCEIVE_RUN)) if meta_path and deferred
                        else (("k_move + k_perceive (cell-meta layout, %d ants per wave) + " % env.query(cm.Q_PERCEIVE_RUN)
                               if meta_path else "k_act + ") + ("k_update_one" if cfg.n_ants <= 1024 else "k_update")),
-                       "policy": ("linear DQN net (F+2 -> 32 -> 3+3) in-loop, bf16 MFMA" if policy is not None
+                       "policy": (("linear DQN net (F+2 -> 32 -> 3+3) in-loop, bf16 MFMA, " +
+                                   ("inside k_perceive (antsrl_set_inloop_policy)" if inloop else "own kernel (antsrl_policy_mlp)"))
+                                  if policy is not None
                                   else "uniform random, pre-generated on device"),
                        "parallelism": "env-sharded x%d, reward/done all-gather (%s)" % (world, args.gather)},
             "roofline": roofline,

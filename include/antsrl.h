@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define ANTSRL_ABI_VERSION 2
+#define ANTSRL_ABI_VERSION 3
 
 #define ANTSRL_MAX_CHANNELS 16
 #define ANTSRL_MAX_PSIDE 15                                      /* 2*radius+1 <= 15 */
@@ -357,6 +357,19 @@ int antsrl_set_activation(AntsHandle *h, const float *act, double new_deposit_st
 int antsrl_policy_mlp(AntsHandle *h, const float *obs, const float *agent_state, int64_t n_ants, int32_t n_features,
                       const float *w1, const float *b1, const float *w2, const float *b2, const float *w3,
                       const float *b3, int8_t *rotation, int8_t *pheromone, float *logits, void *stream);
+
+/* The same network evaluated INSIDE the observation kernel (no reference counterpart; BASELINE config 5's loop:
+ * action = agent.get_action(obs) of main.py:96 for the NEXT step, computed where the rows are produced).  While set,
+ * every antsrl_step / antsrl_step_update / antsrl_observe that writes observations also stores
+ *   rotation_next int8 [E][N] = argmax(layer2(out)) - 1     pheromone_next int8 [E][N] = argmax(layer3(out)) (or NULL)
+ * for the rows it has just written — the values antsrl_policy_mlp returns for that observation tensor, bit for bit
+ * (same bf16 fragments, same order of MFMAs and additions) without re-reading it from HBM.  Needs the cell-meta
+ * path with bfloat16 observations (ANTSRL_Q_CELL_META, antsrl_set_obs_format); ANTSRL_E_UNSUPPORTED otherwise.
+ * The weights (device pointers, float32, row-major like nn.Linear: w1 [32][n_features + 2], w2 / w3 [3][32]) are
+ * copied into the handle's workspace at the call; w1 == NULL switches the in-loop policy off. */
+int antsrl_set_inloop_policy(AntsHandle *h, int32_t n_features, const float *w1, const float *b1, const float *w2,
+                             const float *b2, const float *w3, const float *b3, int8_t *rotation_next,
+                             int8_t *pheromone_next, void *stream);
 
 /* Copies one piece of state into a caller device buffer in the canonical
  * reference-shaped layout (ANTSRL_S_*).  Replaces attribute reads such as

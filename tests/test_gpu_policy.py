@@ -150,3 +150,68 @@ def test_full_config5_shard_policy_in_loop():
     xyt = env.read_state(cm.S_ANTS_XYT).cpu().numpy()
     np.testing.assert_allclose(xyt[pick], orc.ants_xyt, rtol=0, atol=1e-9)
     np.testing.assert_array_equal(env.read_state(cm.S_FOOD).cpu().numpy()[pick], orc.food)
+
+
+@pytest.mark.parametrize("E,N,W,H,R,filt", [
+    (8, 512, 256, 256, 8, None),     # c5's shape: 16 full tiles per env, interleaved cell records
+    (3, 100, 64, 64, 0, None),       # K = 6, a last tile of 4 ants
+    (2, 300, 96, 64, 3, "3x3"),      # explicit sweep mode (separate pheromone / food records), a last tile of 12 ants
+    (16, 40, 48, 48, 2, None),       # a small batch: shorter runs per wave (a tile of fewer than 32 ants per workgroup)
+    (1, 33, 40, 40, 0, None),
+])
+def test_inloop_policy_equals_standalone_kernel(E, N, W, H, R, filt):
+    """antsrl_set_inloop_policy: the net evaluated inside k_perceive on the rows it has just written must return, bit
+    for bit, what antsrl_policy_mlp returns for the stored (bfloat16) observation tensor — in every step, in a
+    standalone observation, with and without the pheromone head; and the rows themselves are unchanged by it."""
+    import torch
+    from antsrl_amd import config as cm
+    from antsrl_amd.batched import BatchedAntsEnv
+    from antsrl_amd.policy import LinearPolicy
+    from antsrl_amd.synth import synth_init
+    kw = dict(n_rocks=R, deposit_strength=256.0, act_path=cm.ACT_CELL_META)
+    if filt == "3x3":
+        f3 = np.ones((3, 3)) * 0.02
+        f3[1, 1] = 1 - 8 * 0.02
+        kw["filt"] = f3 * 0.999
+    cfg = cm.make_cfg(E, N, W, H, **kw)
+    init = synth_init(cfg, seed=5, n_food_discs=6, food_rmin=3, food_rmax=6)
+    env = BatchedAntsEnv(cfg, obs_dtype=torch.bfloat16)
+    plain = BatchedAntsEnv(cfg, obs_dtype=torch.bfloat16)  # the same run without the in-loop policy
+    env.reset(init)
+    plain.reset(init)
+    F = 49 * cfg.n_channels
+    for head in (True, False):
+        pol = LinearPolicy(F, env.device, with_pheromone_head=head, seed=7 + head)
+        pol.attach(env)
+        o, a, _ = env.observe()  # main.py:88: the first observation feeds the first action
+        po, pa, _ = plain.observe()
+        assert torch.equal(o, po) and torch.equal(a, pa)
+        for t in range(5):
+            rot_s, ph_s = pol.act(env.obs, env.agent_state, env=env)
+            assert torch.equal(env.next_rotation, rot_s), "rotation, step %d" % t
+            if head:
+                assert torch.equal(env.next_pheromone, ph_s), "pheromone, step %d" % t
+            else:
+                assert env.next_pheromone is None and ph_s is None
+            rot, ph = env.next_rotation.clone(), (env.next_pheromone.clone() if head else None)
+            o, a, r, d = env.step_update(rot, ph, None)
+            po, pa, pr, pd = plain.step_update(rot, ph, None)
+            assert torch.equal(o, po) and torch.equal(a, pa) and torch.equal(r, pr) and torch.equal(d, pd)
+        pol.detach(env)
+    # detached: observations no longer touch the action buffers
+    env.next_rotation.fill_(7)
+    env.step_update(None, None, None)
+    plain.step_update(None, None, None)
+    assert int(env.next_rotation.min()) == 7 and torch.equal(env.obs, plain.obs)
+
+
+def test_inloop_policy_needs_bfloat16_observations():
+    import torch
+    from antsrl_amd import config as cm
+    from antsrl_amd.batched import BatchedAntsEnv
+    from antsrl_amd.policy import LinearPolicy
+    cfg = cm.make_cfg(2, 64, 64, 64, act_path=cm.ACT_CELL_META)
+    env = BatchedAntsEnv(cfg)  # float32 observations
+    pol = LinearPolicy(49 * cfg.n_channels, env.device)
+    with pytest.raises(AssertionError):
+        pol.attach(env)
