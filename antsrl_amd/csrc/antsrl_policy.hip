@@ -108,9 +108,7 @@ k_policy_mlp(const float *__restrict__ obs, const float *__restrict__ agent_stat
     const int la = lane >> 4, lf = lane & 15;                          // loader role: ant la + 4 i, floats 4 lf .. 4 lf + 3
     const int nchunks = (IN + POL_KC - 1) / POL_KC;
     for (int t0 = wave; t0 < ntiles; t0 += nwaves) {
-        // LAST tile first: the rows k_perceive wrote most recently are the ones still in the 256 MiB Infinity Cache; in
-        // forward order every row's reuse distance is the whole tensor plus the gathers (an LRU's worst case)
-        const int t = newest_first ? ntiles - 1 - t0 : t0;
+        const int t = newest_first ? ntiles - 1 - t0 : t0; // (A/B switch, see antsrl_launch_policy)
         const int ant = min(t * 32 + r, M - 1); // clamped: duplicates are not written back
         const int rows = min(32, M - t * 32);
         const float *tile = obs + (size_t)t * 32 * F;
@@ -347,9 +345,7 @@ k_policy_flat(const float *__restrict__ obs, const float *__restrict__ agent_sta
     const int ntiles = (M + 31) / 32;
     const __bf16 *wrow = w1s + r * KP + 8 * h;
     for (int t0 = wave; t0 < ntiles; t0 += nwaves) {
-        // LAST tile first: the rows k_perceive wrote most recently are the ones still in the 256 MiB Infinity Cache; in
-        // forward order every row's reuse distance is the whole tensor plus the gathers (an LRU's worst case)
-        const int t = newest_first ? ntiles - 1 - t0 : t0;
+        const int t = newest_first ? ntiles - 1 - t0 : t0; // (A/B switch, see antsrl_launch_policy)
         const int ant = min(t * 32 + r, M - 1); // clamped: duplicates are not written back
         const int rows = min(32, M - t * 32);
         const uint32_t nelem = (uint32_t)rows * (uint32_t)F;
@@ -494,7 +490,9 @@ hipError_t antsrl_launch_policy(const float *obs, const float *agent_state, cons
                                 const float *w2, const float *b2, const float *w3, const float *b3, int8_t *rot,
                                 int8_t *ph, float *logits, int M, int F, hipStream_t st, bool obs_bf16)
 {
-    const int newest_first = PROF_ENV("ANTSRL_POLICY_OLDEST_FIRST") ? 0 : 1; // tile order, see the kernels
+    // tile order (profiling switch): newest rows first was tried for Infinity Cache hits on what k_perceive has just
+    // written and measured no better (c5 0.1301 vs 0.1294 ms/step, profiles/r02/policy_order_ab.txt)
+    const int newest_first = PROF_ENV("ANTSRL_POLICY_NEWEST_FIRST") ? 1 : 0;
 
     if (M < 1 || F < 1) return hipErrorInvalidValue;
     {
