@@ -176,6 +176,8 @@ def test_inloop_policy_equals_standalone_kernel(E, N, W, H, R, filt):
     cfg = cm.make_cfg(E, N, W, H, **kw)
     init = synth_init(cfg, seed=5, n_food_discs=6, food_rmin=3, food_rmax=6)
     env = BatchedAntsEnv(cfg, obs_dtype=torch.bfloat16)
+    if env.query(cm.Q_PERCEIVE_RUN) * 4 > 32:
+        pytest.skip("more than 32 ants per k_perceive workgroup (a profiling-library switch): no in-loop policy")
     plain = BatchedAntsEnv(cfg, obs_dtype=torch.bfloat16)  # the same run without the in-loop policy
     env.reset(init)
     plain.reset(init)
