@@ -413,7 +413,8 @@ def test_stencil_shapes_vs_oracle(torch_mod, radius, separable, W, H):
     _compare_with_oracle(torch_mod, cfg, synth_init(cfg, seed=W + H), steps=5, seed=radius, jitter_mode="builtin")
 
 
-@pytest.mark.parametrize("E,N,W,H,rocks", [(6, 512, 256, 256, 8), (3, 100, 64, 48, 2), (2, 1024, 128, 128, 0), (5, 37, 40, 40, 3)])
+@pytest.mark.parametrize("E,N,W,H,rocks", [(6, 512, 256, 256, 8), (3, 100, 64, 48, 2), (2, 1024, 128, 128, 0), (5, 37, 40, 40, 3),
+                                           (16, 64, 48, 48, 2), (32, 100, 40, 56, 0)])  # (multiples of 16 envs: split-batch candidates)
 def test_deferred_update_is_bit_identical(torch_mod, E, N, W, H, rocks):
     """antsrl_update with the library's own wall jitter is deferred into the next step (k_update_move, include/antsrl.h
     "DEFERRED UPDATE").  Handle A runs the loop the way bench.py and main.py do (the update kernel always rides with
