@@ -279,12 +279,11 @@ static void fill_kp(const AntsCfg *c, KP *p)
     p->ps = use_interleaved(c) ? 4 : c->n_phero;
     p->fs = use_interleaved(c) ? 4 : 1;
     p->g_now = p->g_dep = p->inv_g_dep = 1.0;
-    // cell-meta path (k_move + k_perceive) for the reference's perception shapes (AntsCfg.act_path pins either)
-    // Tiny batches (fewer than 8192 ants in all: BASELINE config 1's single 32-ant env) are launch-latency bound:
-    // one kernel fewer wins there (c1: 20.7 us/step with k_act against 25.8 with k_move + k_perceive), so they keep
-    // k_act whenever its LDS plan fits with the grid's bit maps in LDS.
-    const bool tiny = (long long)p->E * p->N < 8192 && antsrl_act_fits(*p) && !antsrl_act_needs_hbm_maps(*p);
-    p->meta = antsrl_meta_supported(*p) && (c->act_path == ANTSRL_ACT_CELL_META || (c->act_path == ANTSRL_ACT_AUTO && !tiny)) ? 1 : 0;
+    // cell-meta path (k_move + k_perceive) for the reference's perception shapes (AntsCfg.act_path pins either).
+    // (Round 2 first kept k_act for batches under 8192 ants — one launch fewer; with the deferred update the cell-meta
+    // path is two launches per step as well and wins at every size: c1 13.8 against 15.3 us/step, 16 envs x 256 ants
+    // 16.2 against 30.1 — profiles/r02/tiny_ab.txt.)
+    p->meta = antsrl_meta_supported(*p) && c->act_path != ANTSRL_ACT_SINGLE_KERNEL ? 1 : 0;
     if (p->meta && p->fs == 1) p->fs = 2;
 }
 

@@ -73,9 +73,10 @@ enum {
 enum { ANTSRL_PHERO_AUTO = 0, ANTSRL_PHERO_EXPLICIT_SWEEP = 1 };
 
 /* Which kernels run RLApi.step / RLApi.observation.  AUTO picks by measurement: the cell-meta path (k_move +
- * k_perceive) wherever it is supported, except for batches of fewer than 8192 ants in all, which are launch-latency
- * bound and keep the single kernel.  The other two values pin a path (antsrl_create refuses a configuration the
- * pinned path does not support): results are identical, both are parity-tested. */
+ * k_perceive) wherever it is supported (the generator's channel order, two pheromone channels, a perception of 128..368
+ * values per ant, at most 4096 ants per environment), the single kernel k_act elsewhere.  The other two values pin a
+ * path (antsrl_create refuses a configuration the pinned path does not support): results are identical, both are
+ * parity-tested. */
 enum { ANTSRL_ACT_AUTO = 0, ANTSRL_ACT_CELL_META = 1, ANTSRL_ACT_SINGLE_KERNEL = 2 };
 
 /* reward kinds (environment/rewards/) */
