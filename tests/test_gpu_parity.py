@@ -468,6 +468,45 @@ def test_deferred_update_is_bit_identical(torch_mod, E, N, W, H, rocks):
     assert phero_close(_cpu(a.read_state(cm.S_PHERO)), orc.phero, threshold=cfg.phero_threshold).all()
 
 
+def test_long_run_crosses_the_explored_stamp_rebase(torch_mod):
+    """The cell-meta path keeps 'explored before observation s' and 'an ant stands here in observation s' as stamps in
+    the cell's META word and re-bases them every 16 381 observations (k_meta_rebase, antsrl_device.h META_NEVER).  A
+    single episode longer than that (max_time is the caller's to choose; the reference has no limit) must cross the
+    re-basing without a trace: exploration rewards (explored map), the presence channel and the final state against
+    the oracle, with every step of the 150 around the crossing compared."""
+    from antsrl_amd import config as cm
+    from antsrl_amd.batched import BatchedAntsEnv
+    from antsrl_amd.synth import random_actions, synth_init
+    from oracle.oracle import Oracle
+    E, N = 2, 8
+    cfg = cm.make_cfg(E, N, 640, 512, n_rocks=2, deposit_strength=256.0, max_time=1 << 30, act_path=cm.ACT_CELL_META)
+    init = synth_init(cfg, seed=21, wall_density=0.04)
+    env = BatchedAntsEnv(cfg)
+    env.reset(init)
+    orc = Oracle(cfg, init, n_threads=2)
+    steps = 16381 + 120
+    rng = np.random.default_rng(4)
+    nonzero_after = 0
+    for t in range(steps):
+        rot = rng.integers(-1, 2, (E, N), dtype=np.int8)
+        ph = rng.integers(0, 3, (E, N), dtype=np.int8)
+        obs, ast, rew, done = env.step_update(rot, ph, None)
+        o_obs, o_ast, o_rew, o_done = orc.step(rot, ph)
+        orc.update(None)
+        if t % 257 == 0 or t > 16381 - 30:
+            ctx = "step %d" % t
+            np.testing.assert_array_equal(_cpu(rew), o_rew.astype(np.float32), err_msg=ctx)
+            go = _cpu(obs)
+            for e in range(E):
+                check_obs(cfg, go[e], o_obs[e], ctx + " env %d" % e)
+            if t > 16381:
+                nonzero_after += int((o_rew > 0).sum())
+    assert nonzero_after > 0, "the episode stopped exploring before the re-basing: the test no longer tests it"
+    np.testing.assert_array_equal(_cpu(env.read_state(cm.S_EXPLORED)), orc.explored)
+    np.testing.assert_allclose(_cpu(env.read_state(cm.S_ANTS_XYT)), orc.ants_xyt, rtol=0, atol=1e-7)
+    np.testing.assert_array_equal(_cpu(env.read_state(cm.S_FOOD)), orc.food)
+
+
 def test_scaled_units_edge_cases(torch_mod):
     """Scaled pheromone units against the oracle where they need care: an initial grid with
     pheromone on wall cells, ants that START on wall cells (their deposits live for exactly one
