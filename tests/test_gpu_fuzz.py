@@ -167,3 +167,48 @@ def test_random_configuration_on_grids_past_the_lds_limit(torch_mod, seed):
     cfg = cm.make_cfg(E, N, W, H, **kw)
     init = synth_init(cfg, seed=seed, n_food_discs=6, food_rmin=2, food_rmax=6, wall_density=0.05)
     _compare_with_oracle(torch_mod, cfg, init, steps=4, seed=seed, jitter_mode="injected")
+
+
+@pytest.mark.parametrize("seed", range(_BASE + 300, _BASE + 300 + max(32, _CASES // 2)))
+def test_random_configuration_library_jitter_no_reads_between_steps(torch_mod, seed):
+    """The random configurations driven the way bench.py does: one antsrl_step_update per step with the library's own
+    wall jitter and NO state read in between, so that every update that can be deferred into the next step is
+    (k_update_move, include/antsrl.h "DEFERRED UPDATE"); outputs of every step and the final state against the oracle,
+    which implements the same counter-based jitter."""
+    from antsrl_amd import config as cm
+    from antsrl_amd.batched import BatchedAntsEnv
+    from antsrl_amd.synth import synth_init
+    from oracle.oracle import Oracle
+    from helpers import phero_close
+    rng = np.random.default_rng(5000 + seed)
+    E, N, W, H, kw = _random_case(rng)
+    kw["n_phero"] = 2
+    if kw["channels"] is not None:
+        kw["channels"] = [(k, a % 2) for k, a in kw["channels"]]
+    if rng.random() < 0.5:  # the generator's own layout: the cell-meta path where the perception shape allows it
+        kw["channels"] = None
+        kw["perception_radius"], kw["mask"] = 3, None
+        kw.pop("phero_max_val", None)  # (pheromone is perceived again: max_val is needed)
+    cfg = cm.make_cfg(E, N, W, H, **kw)
+    init = synth_init(cfg, seed=seed, n_food_discs=4, food_rmin=1, food_rmax=4, wall_density=0.08)
+    env, orc = BatchedAntsEnv(cfg), Oracle(cfg, init)
+    env.reset(init)
+    prev_dist = _anthill_dist(init, orc.ants_xyt)
+    for t in range(7):
+        rot = rng.integers(-1, 2, (E, N), dtype=np.int8)
+        ph = rng.integers(0, 3, (E, N), dtype=np.int8) if t != 4 else None
+        obs, ast, rew, done = env.step_update(rot, ph, None)
+        o_obs, o_ast, o_rew, o_done = orc.step(rot, ph)
+        g = _cpu(obs)
+        for e in range(E):
+            check_obs(cfg, g[e], o_obs[e], "seed %d step %d env %d" % (seed, t, e))
+        np.testing.assert_array_equal(_cpu(ast), o_ast.astype(np.float32))
+        _check_reward(cfg, init, _cpu(rew), o_rew, orc.ants_xyt, prev_dist, "seed %d step %d" % (seed, t))
+        prev_dist = _anthill_dist(init, orc.ants_xyt)
+        np.testing.assert_array_equal(_cpu(done), o_done)
+        orc.update(None)
+    assert phero_close(_cpu(env.read_state(cm.S_PHERO)), orc.phero, threshold=cfg.phero_threshold).all()
+    np.testing.assert_allclose(_cpu(env.read_state(cm.S_ANTS_XYT)), orc.ants_xyt, rtol=0, atol=1e-9)
+    np.testing.assert_array_equal(_cpu(env.read_state(cm.S_FOOD)), orc.food)
+    np.testing.assert_array_equal(_cpu(env.read_state(cm.S_ANTHILL_FOOD)), orc.anthill_food)
+    np.testing.assert_array_equal(_cpu(env.read_state(cm.S_EXPLORED)), orc.explored)
