@@ -33,10 +33,11 @@ __host__ __device__ inline size_t move_lds_bytes(int HT, int N)
 }
 
 template <int C>
-__device__ __forceinline__ void move_body(const KP &p, const int8_t *__restrict__ rotation, const int8_t *__restrict__ phero_act,
-                                          uint8_t *__restrict__ done, const int do_step, const uint32_t seq, unsigned char *smem)
+__device__ __forceinline__ void move_body(const KP &p, const int e, const int8_t *__restrict__ rotation,
+                                          const int8_t *__restrict__ phero_act, uint8_t *__restrict__ done, const int do_step,
+                                          const uint32_t seq, unsigned char *smem)
 {
-    const int e = blockIdx.x, tid = threadIdx.x, T = blockDim.x;
+    const int tid = threadIdx.x, T = blockDim.x;
     const int N = p.N, W = p.W, H = p.H, K = p.K;
     const size_t G = (size_t)W * H, eN = (size_t)e * N;
     uint32_t *hkeys = (uint32_t *)smem, *hvals = hkeys + p.HT;
@@ -175,7 +176,7 @@ k_move(const KP p, const int8_t *__restrict__ rotation, const int8_t *__restrict
        uint8_t *__restrict__ done, const int do_step, const uint32_t seq)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    move_body<C>(p, rotation, phero_act, done, do_step, seq, smem);
+    move_body<C>(p, env_of_block(blockIdx.x, p.E, seq), rotation, phero_act, done, do_step, seq, smem);
 }
 
 // Environment.update of step t (deferred by the host, include/antsrl.h "deferred update") and the move of step t + 1
@@ -190,9 +191,10 @@ k_update_move(const KP p, const int out_buf, const double g_dep, const double in
               const int8_t *__restrict__ phero_act, uint8_t *__restrict__ done, const uint32_t seq)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    update_one_body<C>(p, nullptr, out_buf, smem, g_dep, inv_g_dep);
+    const int e = env_of_block(blockIdx.x, p.E, seq);
+    update_one_body<C>(p, e, nullptr, out_buf, smem, g_dep, inv_g_dep);
     __syncthreads(); // the update's global writes are visible to the whole workgroup; its LDS is dead
-    move_body<C>(p, rotation, phero_act, done, 1, seq, smem);
+    move_body<C>(p, e, rotation, phero_act, done, 1, seq, smem);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -340,6 +342,7 @@ k_perceive(const KP p, const float *__restrict__ cells, float *__restrict__ obs,
             e = b / nseg;
             seg = b % nseg;
         }
+        e = env_of_block(e, p.E, seq); // (odd observations from the other end: antsrl_util.h)
     }
     const PrcOff lo = prc_offsets(run, PP, K, R, nwaves, POLICY);
     double *rock = (double *)(smem + lo.rock);

@@ -17,7 +17,7 @@ __global__ void __launch_bounds__(1024)
 k_update_one(const KP p, const double *__restrict__ wall_jitter, const int out_buf)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    update_one_body<C>(p, wall_jitter, out_buf, smem, p.g_dep, p.inv_g_dep);
+    update_one_body<C>(p, blockIdx.x, wall_jitter, out_buf, smem, p.g_dep, p.inv_g_dep);
 }
 
 // Anthill.update over the WHOLE grid (anthill.py:41-46): needed on the first update after a

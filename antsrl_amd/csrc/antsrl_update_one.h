@@ -20,11 +20,12 @@ __host__ __device__ inline size_t update_one_lds_bytes(int HT, int R, int nwaves
 // round trip behind each barrier) — it remains the path for N > 1024 and for the fused launch.
 // `g_dep` / `inv_g_dep`: KP::g_dep / inv_g_dep as they stood at the update's own call (a deferred update runs after the
 // host has advanced them for the next observation).
+// `e`: the environment of this workgroup (blockIdx.x, or counted from the other end: env_of_block in antsrl_util.h).
 template <int C>
-__device__ __forceinline__ void update_one_body(const KP &p, const double *__restrict__ wall_jitter, const int out_buf,
+__device__ __forceinline__ void update_one_body(const KP &p, const int e, const double *__restrict__ wall_jitter, const int out_buf,
                                                 unsigned char *smem, const double g_dep, const double inv_g_dep)
 {
-    const int e = blockIdx.x, tid = threadIdx.x, T = blockDim.x;
+    const int tid = threadIdx.x, T = blockDim.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwaves = T >> 6;
     const int N = p.N, W = p.W, H = p.H, R = p.R;
     const size_t G = (size_t)W * H, eN = (size_t)e * N;

@@ -164,3 +164,19 @@ static inline unsigned grid_for(size_t n)
     if (b < 1) b = 1;
     return (unsigned)b;
 }
+
+// The environment a workgroup (or a k_perceive workgroup's environment slot) `i` of `E` takes in observation `seq`: odd
+// observations walk the environments from the other end.  The batch's per-step working set (c3: ~240 MB of cell-record
+// lines + ~60 MB of ant state, nearly the same lines every step) is a little larger than the 256 MiB Infinity Cache; an
+// LRU cycled in ONE direction over slightly more than its capacity hits almost never, walked back and forth it keeps the
+// most recently used end (measured: k_perceive 0.2325 -> 0.2238 ms on c3, -3.8 % per step at 768 envs;
+// profiles/r02/altorder_ab.txt).  Speed only: any order gives the same results.
+__device__ __forceinline__ int env_of_block(const int i, const int E, const uint32_t seq)
+{
+#ifdef ANTSRL_ENV_ORDER_FORWARD // (variant build for the A/B)
+    (void)E; (void)seq;
+    return i;
+#else
+    return (seq & 1u) ? E - 1 - i : i;
+#endif
+}
