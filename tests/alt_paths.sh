@@ -15,7 +15,7 @@ rc=0
 for v in ANTSRL_FUSE_UPDATE=1 ANTSRL_UPDATE_LOOPS=1 ANTSRL_POLICY_CHUNKED=1 ANTSRL_NO_SEPARABLE=1 ANTSRL_SWEEP_TILED=1 ANTSRL_NO_INTERLEAVE=1 \
          ANTSRL_SWEEP_ONE_COLUMN=1 ANTSRL_SWEEP_SEG=7 ANTSRL_PRC_RUN=32 ANTSRL_NO_DEFER_UPDATE=1; do
   echo "== $v"
-  env $v python3 -m pytest tests -m gpu -q -x 2>&1 | tail -2
+  env $v python3 -m pytest tests -m gpu -q -x 2>&1 | grep -v '^\.\|^$' | tail -4
   [ ${PIPESTATUS[0]} -ne 0 ] && rc=1
 done
 exit $rc

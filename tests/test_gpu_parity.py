@@ -429,7 +429,8 @@ def test_deferred_update_is_bit_identical(torch_mod, E, N, W, H, rocks):
     cfg = cm.make_cfg(E, N, W, H, n_rocks=rocks, deposit_strength=256.0, reward_kind=cm.REWARD_ALL, act_path=cm.ACT_CELL_META)
     init = synth_init(cfg, seed=31 + N, wall_density=0.08)
     a, b = BatchedAntsEnv(cfg), BatchedAntsEnv(cfg)
-    assert a.query(cm.Q_DEFERRED_UPDATE) == 1
+    if a.query(cm.Q_DEFERRED_UPDATE) != 1:
+        pytest.skip("updates are not deferred (ANTSRL_NO_DEFER_UPDATE in the profiling library)")
     a.reset(init)
     b.reset(init)
     orc = Oracle(cfg, init, n_threads=4)
