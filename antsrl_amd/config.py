@@ -18,7 +18,7 @@ from typing import Optional, Sequence
 
 import numpy as np
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 MAX_CHANNELS = 16
 MAX_PSIDE = 15
 MAX_PCELLS = MAX_PSIDE * MAX_PSIDE
@@ -78,6 +78,8 @@ class AntsCfg(C.Structure):
         ("fct_headinganthill", C.c_double),
         ("rng_seed", C.c_uint64),
         ("act_path", C.c_int32),
+        ("env_id_base", C.c_int32),
+        ("n_envs_total", C.c_int32),
         ("_pad1", C.c_int32),
     ]
 
@@ -173,8 +175,12 @@ def make_cfg(n_envs: int, n_ants: int, w: int, h: int, *, n_phero: int = 2, n_ro
              reward_threshold: float = 1.0, fct_explore: float = 1.0, fct_food: float = 1.0,
              fct_anthill: float = 5.0, fct_explore_holding: float = 0.0,
              fct_headinganthill: float = 1.0, rng_seed: int = 0x5EED,
-             phero_mode: int = PHERO_AUTO, act_path: int = ACT_AUTO) -> AntsCfg:
-    """Build an AntsCfg with the reference's defaults (see module docstring)."""
+             phero_mode: int = PHERO_AUTO, act_path: int = ACT_AUTO, env_id_base: int = 0,
+             n_envs_total: int = 0) -> AntsCfg:
+    """Build an AntsCfg with the reference's defaults (see module docstring).
+    env_id_base: the GLOBAL id of this handle's environment 0 (a shard of envs [lo, hi) passes lo): every random stream
+    the library keys on an environment takes env_id_base + e, so sharding cannot change a result (include/antsrl.h).
+    n_envs_total: environments of the whole sharded batch (0 = env_id_base + n_envs)."""
     c = AntsCfg()
     c.abi_version = ABI_VERSION
     c.n_envs, c.n_ants, c.w, c.h = n_envs, n_ants, w, h
@@ -234,6 +240,8 @@ def make_cfg(n_envs: int, n_ants: int, w: int, h: int, *, n_phero: int = 2, n_ro
     c.rng_seed = rng_seed
     c.phero_mode = phero_mode
     c.act_path = act_path
+    c.env_id_base = env_id_base
+    c.n_envs_total = n_envs_total
     return c
 
 

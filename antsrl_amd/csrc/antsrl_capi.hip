@@ -51,6 +51,7 @@ struct AntsHandle {
     int steps_since_update;// RLApi.step calls since the last Environment.update
     bool need_full_collect;// next update must run Anthill.update over the whole grid
     bool is_reset;
+    bool episode_over;     // a refused auto-reset left a finished episode behind (see antsrl_step_update)
     size_t ws_bytes;
     AntsGen gen;           // device generator parameters (antsrl_generate)
     bool has_gen;
@@ -126,6 +127,11 @@ static int validate(const AntsCfg *c)
         return fail(ANTSRL_E_INVALID, "bad reward_kind");
     if (c->has_max_val && !(c->phero_max_val > 0)) return fail(ANTSRL_E_INVALID, "phero_max_val must be > 0");
     if (c->act_path < ANTSRL_ACT_AUTO || c->act_path > ANTSRL_ACT_SINGLE_KERNEL) return fail(ANTSRL_E_INVALID, "bad act_path");
+    if (c->env_id_base < 0 || (long long)c->env_id_base + c->n_envs > 0x7fffffffll)
+        return fail(ANTSRL_E_INVALID, "env_id_base must be >= 0 and env_id_base + n_envs must fit 31 bits");
+    if (c->n_envs_total != 0 && (long long)c->n_envs_total < (long long)c->env_id_base + c->n_envs)
+        return fail(ANTSRL_E_INVALID, "n_envs_total %d < env_id_base + n_envs = %lld (0 = that sum)", c->n_envs_total,
+                    (long long)c->env_id_base + c->n_envs);
     if (c->act_path == ANTSRL_ACT_CELL_META) {
         KP kp;
         fill_kp(c, &kp);
@@ -275,6 +281,7 @@ static void fill_kp(const AntsCfg *c, KP *p)
         }
     }
     p->rng_seed = c->rng_seed;
+    p->env_id_base = (uint32_t)c->env_id_base;
     p->scaled = use_scaled(c) ? 1 : 0;
     p->ps = use_interleaved(c) ? 4 : c->n_phero;
     p->fs = use_interleaved(c) ? 4 : 1;
@@ -323,7 +330,7 @@ extern "C" int antsrl_create(const AntsCfg *cfg, void *workspace, size_t workspa
     h->cfg = *cfg;
     fill_kp(cfg, &h->p);
     carve(cfg, &h->p.s, (unsigned char *)workspace);
-    h->cur = 0; h->steps_since_update = 0; h->need_full_collect = true; h->is_reset = false; h->pend_update = false;
+    h->cur = 0; h->steps_since_update = 0; h->need_full_collect = true; h->is_reset = false; h->episode_over = false; h->pend_update = false;
     h->pol = PolArgs{};
     h->sweeps = 0; h->need_wall_clear = false;
     h->has_gen = false; h->episode_seed = 0; h->host_timestep = 1; h->obs_bf16 = false;
@@ -353,24 +360,33 @@ extern "C" int antsrl_reset(AntsHandle *h, const AntsInit *init, void *stream)
     hipError_t e = antsrl_launch_reset(h->p, init, (hipStream_t)stream);
     if (e != hipSuccess) return hip_fail(e, "reset");
     h->p.deposit_strength = h->cfg.deposit_strength;
-    h->cur = 0; h->steps_since_update = 0; h->need_full_collect = true; h->is_reset = true;
+    h->cur = 0; h->steps_since_update = 0; h->need_full_collect = true; h->is_reset = true; h->episode_over = false;
     h->sweeps = 0; h->need_wall_clear = h->p.scaled && init->phero != nullptr;
     h->host_timestep = 1; h->obs_seq = 0;
     set_decay(h);
     return ANTSRL_OK;
 }
 
+// np.random.seed(seed * 5) takes 32 bits (environment_generator.py:55): env e draws from seed + env_id_base + e.  Checked at
+// every (auto-)reset: numpy raises past 2^32, a wrapped seed would silently replay an earlier episode.  (Written so that
+// no intermediate can wrap in uint64.)
+static int check_gen_seed(const AntsHandle *h, const AntsGen &g, uint64_t seed)
+{
+    const uint64_t top = (uint64_t)h->p.env_id_base + (uint64_t)h->p.E; // < 2^31
+    if (g.rng_kind == ANTSRL_RNG_REFERENCE && (seed > 0xFFFFFFFFull / 5u || seed > 0xFFFFFFFFull / 5u - top))
+        return fail(ANTSRL_E_INVALID, "ANTSRL_RNG_REFERENCE: (episode_seed + env_id_base + n_envs) * 5 must stay below 2^32 (np.random.seed)");
+    return ANTSRL_OK;
+}
+
 static int do_generate(AntsHandle *h, uint64_t seed, hipStream_t st)
 {
-    // np.random.seed(seed * 5) takes 32 bits (environment_generator.py:55): env e draws from seed + e.  Checked at every
-    // (auto-)reset: numpy raises past 2^32, a wrapped seed would silently replay an earlier episode.
-    if (h->gen.rng_kind == ANTSRL_RNG_REFERENCE && (seed + (uint64_t)h->p.E) * 5u > 0xFFFFFFFFull)
-        return fail(ANTSRL_E_INVALID, "ANTSRL_RNG_REFERENCE: (episode_seed + n_envs) * 5 must stay below 2^32 (np.random.seed)");
+    int rc = check_gen_seed(h, h->gen, seed);
+    if (rc) return rc;
     h->pend_update = false; // (a deferred update of the state being replaced)
     hipError_t e = antsrl_launch_generate(h->p, h->gen, seed, st);
     if (e != hipSuccess) return hip_fail(e, "generate");
     h->p.deposit_strength = h->cfg.deposit_strength;
-    h->cur = 0; h->steps_since_update = 0; h->need_full_collect = true; h->is_reset = true;
+    h->cur = 0; h->steps_since_update = 0; h->need_full_collect = true; h->is_reset = true; h->episode_over = false;
     h->sweeps = 0; h->need_wall_clear = false; h->host_timestep = 1; h->obs_seq = 0;
     h->episode_seed = seed;
     set_decay(h);
@@ -403,6 +419,8 @@ extern "C" int antsrl_generate(AntsHandle *h, const AntsGen *gen, uint64_t episo
                                               "ANTSRL_WALLS_PERLIN, ANTSRL_WALLS_INPUT or wall_density 0");
         // (the 32-bit limit of np.random.seed(seed * 5) is checked in do_generate, for this and every auto-reset episode)
     }
+    int rc = check_gen_seed(h, *gen, episode_seed); // (before anything of the handle changes: a refused call leaves it as it was)
+    if (rc) return rc;
     h->gen = *gen;
     h->has_gen = true;
     return do_generate(h, episode_seed, (hipStream_t)stream);
@@ -437,7 +455,13 @@ static int flush_pending(AntsHandle *h, hipStream_t st)
     return ANTSRL_OK;
 }
 
-static int not_reset() { return fail(ANTSRL_E_INVALID, "antsrl_reset has not been called on this handle"); }
+static int not_reset(const AntsHandle *h)
+{
+    if (h->episode_over)
+        return fail(ANTSRL_E_INVALID, "the episode is over and its auto-reset was refused (episode seed past np.random.seed's 32 bits): "
+                                      "call antsrl_reset or antsrl_generate");
+    return fail(ANTSRL_E_INVALID, "antsrl_reset has not been called on this handle");
+}
 
 // One observation on the cell-meta path: k_move (with the action phases when `stepping`) then k_perceive.
 static int meta_observe(AntsHandle *h, const int8_t *rot, const int8_t *ph, float *obs, float *agent_state,
@@ -548,7 +572,7 @@ extern "C" int antsrl_step(AntsHandle *h, const int8_t *rotation, const int8_t *
                            float *agent_state, float *reward, uint8_t *done, void *stream)
 {
     if (!h) return fail(ANTSRL_E_INVALID, "NULL handle");
-    if (!h->is_reset) return not_reset();
+    if (!h->is_reset) return not_reset(h);
     if (!agent_state || !reward || !done) return fail(ANTSRL_E_INVALID, "agent_state, reward, done are required");
     return do_step(h, rotation, phero, obs, agent_state, reward, done, (hipStream_t)stream);
 }
@@ -556,7 +580,7 @@ extern "C" int antsrl_step(AntsHandle *h, const int8_t *rotation, const int8_t *
 extern "C" int antsrl_observe(AntsHandle *h, float *obs, float *agent_state, float *reward, void *stream)
 {
     if (!h) return fail(ANTSRL_E_INVALID, "NULL handle");
-    if (!h->is_reset) return not_reset();
+    if (!h->is_reset) return not_reset(h);
     if (h->p.meta)
         return meta_observe(h, nullptr, nullptr, obs, agent_state, reward, nullptr, false, (hipStream_t)stream, false);
     hipError_t e = antsrl_launch_act(h->p, nullptr, nullptr, h->cur, obs, agent_state, reward, nullptr,
@@ -570,7 +594,7 @@ extern "C" int antsrl_observe(AntsHandle *h, float *obs, float *agent_state, flo
 extern "C" int antsrl_update(AntsHandle *h, const double *wall_jitter, void *stream)
 {
     if (!h) return fail(ANTSRL_E_INVALID, "NULL handle");
-    if (!h->is_reset) return not_reset();
+    if (!h->is_reset) return not_reset(h);
     return do_update(h, wall_jitter, (hipStream_t)stream, false, false, true);
 }
 
@@ -585,7 +609,7 @@ extern "C" int antsrl_step_update(AntsHandle *h, const int8_t *rotation, const i
                                   uint8_t *done, void *stream)
 {
     if (!h) return fail(ANTSRL_E_INVALID, "NULL handle");
-    if (!h->is_reset) return not_reset();
+    if (!h->is_reset) return not_reset(h);
     if (!agent_state || !reward || !done) return fail(ANTSRL_E_INVALID, "agent_state, reward, done are required");
     hipStream_t st = (hipStream_t)stream;
     const bool timed = h->ev_armed;
@@ -619,10 +643,19 @@ extern "C" int antsrl_step_update(AntsHandle *h, const int8_t *rotation, const i
     const bool regen = was_done && h->has_gen && h->gen.auto_reset;
     rc = do_update(h, wall_jitter, st, true, fuse, !regen);
     if (timed) (void)hipEventRecord(h->ev[4], st);
-    if (rc == ANTSRL_OK && regen)
-        // next episode, like main.py:69-79 does per episode (reference streams: env e takes seed + e, so the next
-        // episode starts E seeds further)
-        rc = do_generate(h, h->episode_seed + (h->gen.rng_kind == ANTSRL_RNG_REFERENCE ? (uint64_t)h->p.E : 1u), st);
+    if (rc == ANTSRL_OK && regen) {
+        // next episode, like main.py:69-79 does per episode (reference streams: global env g takes seed + g, so the next
+        // episode starts one whole batch — AntsCfg.n_envs_total, all shards — of seeds further)
+        const uint64_t total = h->cfg.n_envs_total ? (uint64_t)h->cfg.n_envs_total : (uint64_t)h->p.env_id_base + (uint64_t)h->p.E;
+        rc = do_generate(h, h->episode_seed + (h->gen.rng_kind == ANTSRL_RNG_REFERENCE ? total : 1u), st);
+        if (rc != ANTSRL_OK) {
+            // The step and the update have run, the next episode could not be drawn (the 32-bit seed limit): the handle
+            // holds a finished episode.  Every later step fails loudly until antsrl_reset / antsrl_generate gives it a
+            // new one, instead of running past max_time with `done` never firing again.
+            h->is_reset = false;
+            h->episode_over = true;
+        }
+    }
     return rc;
 }
 
@@ -663,7 +696,7 @@ extern "C" int antsrl_set_timing_events(AntsHandle *h, void *const *events)
 extern "C" int antsrl_set_activation(AntsHandle *h, const float *act, double new_deposit_strength, void *stream)
 {
     if (!h || !act) return fail(ANTSRL_E_INVALID, "NULL handle or act");
-    if (!h->is_reset) return not_reset();
+    if (!h->is_reset) return not_reset(h);
     int frc = flush_pending(h, (hipStream_t)stream); // (the deferred update deposits with the activation as it was)
     if (frc) return frc;
     hipError_t e = antsrl_launch_set_activation(h->p, act, (hipStream_t)stream);
@@ -755,7 +788,7 @@ extern "C" int antsrl_state_bytes(const AntsHandle *h, int which, size_t *bytes)
 extern "C" int antsrl_read_state(AntsHandle *h, int which, void *dst, void *stream)
 {
     if (!h || !dst) return fail(ANTSRL_E_INVALID, "NULL handle or dst");
-    if (!h->is_reset) return not_reset();
+    if (!h->is_reset) return not_reset(h);
     if (which < 0 || which >= ANTSRL_S_COUNT_) return fail(ANTSRL_E_INVALID, "bad state selector %d", which);
     if (state_bytes(h, which) == 0) return ANTSRL_OK;
     int frc = flush_pending(h, (hipStream_t)stream);

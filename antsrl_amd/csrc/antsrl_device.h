@@ -114,6 +114,7 @@ struct KP {
     double fct_explore, fct_food, fct_anthill, fct_explore_holding, fct_heading;
     double filter[ANTSRL_MAX_FILTER_TAPS];
     uint64_t rng_seed;
+    uint32_t env_id_base, _pad0; // AntsCfg.env_id_base: environment e of this handle is GLOBAL environment env_id_base + e (every env-keyed random stream)
     // Scaled pheromone representation (ANTSRL_PHERO_AUTO with a centre-only filter): the grid
     // holds u = v / f0^S_at_write; v_now = u * g_now with g = f0^S.  g == 1 in explicit mode.
     int32_t scaled, _pad;

@@ -99,26 +99,27 @@ __global__ void k_gen_env(const KP p, const AntsGen g, const uint64_t seed)
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= p.E) return;
     const int W = p.W, H = p.H, m = W < H ? W : H;
-    p.s.anthill_xyr[3 * e + 0] = (int)(gen_u01(seed, e, GEN_ANTHILL, 0) * W * 0.5 + W * 0.25);
-    p.s.anthill_xyr[3 * e + 1] = (int)(gen_u01(seed, e, GEN_ANTHILL, 1) * H * 0.5 + H * 0.25);
-    p.s.anthill_xyr[3 * e + 2] = (int)(gen_u01(seed, e, GEN_ANTHILL, 2) * m * 0.05 + m * 0.05);
+    const uint32_t ge = p.env_id_base + (uint32_t)e; // the env's GLOBAL id keys its streams (AntsCfg.env_id_base)
+    p.s.anthill_xyr[3 * e + 0] = (int)(gen_u01(seed, ge, GEN_ANTHILL, 0) * W * 0.5 + W * 0.25);
+    p.s.anthill_xyr[3 * e + 1] = (int)(gen_u01(seed, ge, GEN_ANTHILL, 1) * H * 0.5 + H * 0.25);
+    p.s.anthill_xyr[3 * e + 2] = (int)(gen_u01(seed, ge, GEN_ANTHILL, 2) * m * 0.05 + m * 0.05);
     p.s.anthill_food[e] = 0.0;
     p.s.timestep[e] = 1; // environment.py:27
     p.s.reward_primed[e] = 0;
     for (int q = 0; q < p.R; ++q) {
-        p.s.rock_cx[(size_t)e * p.R + q] = gen_u01(seed, e, GEN_ROCKS, 4 * q + 0) * (W * 0.75) + W * 0.25;
-        p.s.rock_cy[(size_t)e * p.R + q] = gen_u01(seed, e, GEN_ROCKS, 4 * q + 1) * (H * 0.25) + H * 0.25;
-        p.s.rock_r[(size_t)e * p.R + q] = gen_u01(seed, e, GEN_ROCKS, 4 * q + 2) * 5 + 5;
-        p.s.rock_w[(size_t)e * p.R + q] = gen_u01(seed, e, GEN_ROCKS, 4 * q + 3) * 50 + 50;
+        p.s.rock_cx[(size_t)e * p.R + q] = gen_u01(seed, ge, GEN_ROCKS, 4 * q + 0) * (W * 0.75) + W * 0.25;
+        p.s.rock_cy[(size_t)e * p.R + q] = gen_u01(seed, ge, GEN_ROCKS, 4 * q + 1) * (H * 0.25) + H * 0.25;
+        p.s.rock_r[(size_t)e * p.R + q] = gen_u01(seed, ge, GEN_ROCKS, 4 * q + 2) * 5 + 5;
+        p.s.rock_w[(size_t)e * p.R + q] = gen_u01(seed, ge, GEN_ROCKS, 4 * q + 3) * 50 + 50;
     }
     for (int d = 0; d < g.n_food_discs; ++d) {
-        int rad = (int)(gen_u01(seed, e, GEN_FOOD, 3 * d + 0) * (g.food_rmax - g.food_rmin) + g.food_rmin);
+        int rad = (int)(gen_u01(seed, ge, GEN_FOOD, 3 * d + 0) * (g.food_rmax - g.food_rmin) + g.food_rmin);
         const int cap = (m - 1) / 2;
         rad = rad > cap ? cap : rad;
         int32_t *dd = p.s.gen_discs + ((size_t)e * ANTSRL_MAX_FOOD_DISCS + d) * 3;
         dd[0] = rad;
-        dd[1] = (int)(gen_u01(seed, e, GEN_FOOD, 3 * d + 1) * (W - 2 * rad) + rad);
-        dd[2] = (int)(gen_u01(seed, e, GEN_FOOD, 3 * d + 2) * (H - 2 * rad) + rad);
+        dd[1] = (int)(gen_u01(seed, ge, GEN_FOOD, 3 * d + 1) * (W - 2 * rad) + rad);
+        dd[2] = (int)(gen_u01(seed, ge, GEN_FOOD, 3 * d + 2) * (H - 2 * rad) + rad);
     }
 }
 
@@ -240,7 +241,7 @@ __global__ void __launch_bounds__(64) k_gen_mt(const KP p, const AntsGen g, cons
     __shared__ int s_ar;
     const int e = blockIdx.x, lane = threadIdx.x;
     const int W = p.W, H = p.H, N = p.N, R = p.R, m = W < H ? W : H;
-    const uint64_t seed = seed0 + (uint64_t)e;
+    const uint64_t seed = seed0 + (uint64_t)p.env_id_base + (uint64_t)e; // EnvironmentGenerator(seed = episode_seed + GLOBAL env id)
     const size_t eN = (size_t)e * N;
 
     // ---- Python stream: anthill (:60-63), PerlinGenerator's offsets (map_generators.py:19-20), food circles (:37-39)
@@ -338,8 +339,8 @@ __global__ void k_gen_cells(const KP p, const AntsGen g, const uint64_t seed)
         // PerlinGenerator.generate: random.randint(-10000, 10000) twice (map_generators.py:19-20); with the
         // reference's streams k_gen_mt drew them from the environment's Python generator
         const bool ref_rng = g.rng_kind == ANTSRL_RNG_REFERENCE;
-        const long pox = ref_rng ? (long)p.s.gen_perlin[2 * e + 0] : (long)(gen_u01(seed, (uint32_t)e, GEN_WALL_OFFSET, 0) * 20001.0) - 10000;
-        const long poy = ref_rng ? (long)p.s.gen_perlin[2 * e + 1] : (long)(gen_u01(seed, (uint32_t)e, GEN_WALL_OFFSET, 1) * 20001.0) - 10000;
+        const long pox = ref_rng ? (long)p.s.gen_perlin[2 * e + 0] : (long)(gen_u01(seed, p.env_id_base + (uint32_t)e, GEN_WALL_OFFSET, 0) * 20001.0) - 10000;
+        const long poy = ref_rng ? (long)p.s.gen_perlin[2 * e + 1] : (long)(gen_u01(seed, p.env_id_base + (uint32_t)e, GEN_WALL_OFFSET, 1) * 20001.0) - 10000;
         uint32_t wb = 0, ab = 0;
         for (int b = 0; b < 32; ++b) {
             const size_t cell = w * 32 + b;
@@ -348,7 +349,7 @@ __global__ void k_gen_cells(const KP p, const AntsGen g, const uint64_t seed)
             const bool area = ar >= 0 && (ax - x) * (ax - x) + (ay - y) * (ay - y) <= ar * ar;
             const bool wall = !area && (g.wall_kind == ANTSRL_WALLS_PERLIN  ? perlin_at(x, y, pox, poy, g) > g.wall_density
                                         : g.wall_kind == ANTSRL_WALLS_INPUT ? g.walls_input[e * G + cell] != 0
-                                        : g.wall_density > 0.0 && gen_u01(seed, (uint32_t)e, GEN_WALLS, (uint32_t)cell) < g.wall_density);
+                                        : g.wall_density > 0.0 && gen_u01(seed, p.env_id_base + (uint32_t)e, GEN_WALLS, (uint32_t)cell) < g.wall_density);
             bool fd = false;
             for (int d = 0; d < g.n_food_discs; ++d) {
                 const long rad = discs[3 * d], dx = discs[3 * d + 1] - x, dy = discs[3 * d + 2] - y;
@@ -380,16 +381,17 @@ __global__ void k_gen_ants(const KP p, const uint64_t seed)
         const uint32_t e = (uint32_t)(i / p.N), a = (uint32_t)(i - (size_t)e * p.N);
         const double ax = (double)p.s.anthill_xyr[3 * e + 0], ay = (double)p.s.anthill_xyr[3 * e + 1];
         const double ar = (double)p.s.anthill_xyr[3 * e + 2];
-        const double ang = gen_u01(seed, e, GEN_ANT_ANGLE, a) * 2 * PI_D;
-        const double dist = gen_u01(seed, e, GEN_ANT_DIST, a) * ar * 0.8;
+        const uint32_t ge = p.env_id_base + e;
+        const double ang = gen_u01(seed, ge, GEN_ANT_ANGLE, a) * 2 * PI_D;
+        const double dist = gen_u01(seed, ge, GEN_ANT_DIST, a) * ar * 0.8;
         const double x = warp_coord(cos(ang) * dist + ax, (double)p.W);
         const double y = warp_coord(sin(ang) * dist + ay, (double)p.H);
         p.s.x[i] = x; p.s.y[i] = y;
-        p.s.theta[i] = gen_u01(seed, e, GEN_ANT_THETA, a) * 2 * PI_D;
+        p.s.theta[i] = gen_u01(seed, ge, GEN_ANT_THETA, a) * 2 * PI_D;
         p.s.prev_x[i] = x; p.s.prev_y[i] = y;
         p.s.holding[i] = 0.0f; p.s.prev_holding[i] = 0.0f;
         p.s.mandibles[i] = 0; p.s.reward_state[i] = 0;
-        p.s.seed[i] = (float)gen_u01(seed, e, GEN_ANT_SEED, a);
+        p.s.seed[i] = (float)gen_u01(seed, ge, GEN_ANT_SEED, a);
         p.s.dirty_cell[i] = -1;
         p.s.walldep_cell[i] = -1;
         for (int c = 0; c < p.C; ++c) p.s.activation[i * p.C + c] = 0.0f;

@@ -66,7 +66,7 @@ __device__ __forceinline__ void update_env(const KP &p, const int e, const doubl
             carry += tot;
             if (hit) u = wall_jitter[eN + rank];
         } else if (hit) {
-            u = jitter_u01(p.rng_seed, (uint32_t)e, (uint32_t)ts, (uint32_t)i);
+            u = jitter_u01(p.rng_seed, p.env_id_base + (uint32_t)e, (uint32_t)ts, (uint32_t)i); // (the env's GLOBAL id)
         }
         if (hit) {
             p.s.x[eN + i] = p.s.prev_x[eN + i];

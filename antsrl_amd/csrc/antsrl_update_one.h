@@ -81,7 +81,7 @@ __device__ __forceinline__ void update_one_body(const KP &p, const int e, const 
         const uint32_t rank = block_excl_scan_flag(hit, wave_tot, lane, wave, nwaves, &tot);
         if (hit) u = wall_jitter[eN + rank];
     } else if (hit) {
-        u = jitter_u01(p.rng_seed, (uint32_t)e, (uint32_t)ts, (uint32_t)tid);
+        u = jitter_u01(p.rng_seed, p.env_id_base + (uint32_t)e, (uint32_t)ts, (uint32_t)tid); // (the env's GLOBAL id)
     }
     bool moved = hit;
     if (hit) {

@@ -29,6 +29,16 @@ def shard_range(n_envs_total: int, rank: int, world: int) -> Tuple[int, int]:
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def shard_cfg(n_envs_total: int, rank: int, world: int, n_ants: int, w: int, h: int, **make_cfg_kwargs):
+    """AntsCfg of `rank`'s block of a batch of n_envs_total environments: n_envs = the block's size, env_id_base = its
+    first GLOBAL environment id, n_envs_total = the whole batch — so every environment-keyed random stream of the
+    library (wall jitter, device generators, auto-reset seeds) is the one the unsharded batch would use and sharding
+    cannot change a result (include/antsrl.h, AntsCfg.env_id_base).  -> (cfg, lo, hi)."""
+    from .config import make_cfg
+    lo, hi = shard_range(n_envs_total, rank, world)
+    return make_cfg(hi - lo, n_ants, w, h, env_id_base=lo, n_envs_total=n_envs_total, **make_cfg_kwargs), lo, hi
+
+
 class RewardGather:
     """Pre-allocated all-gather of (reward, done) across the ranks that share an env batch."""
 

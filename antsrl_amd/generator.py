@@ -8,7 +8,7 @@ order, from the same global `random` / `np.random` streams as the reference
 once (antsrl_reset) and wires the RLApi / Environment views.
 
 Extensions over the reference (none changes its behaviour for the reference's arguments):
-  * n_envs > 1 builds a batch; env e is drawn with seed + e (seed=None: fresh randomness each);
+  * n_envs > 1 builds a batch; env e is drawn with seed + env_id_base + e (seed=None: fresh randomness each);
   * n_rocks > 0 works.  The reference's rock branch raises NameError (`n_rocks` undefined at
     environment_generator.py:83-84); this follows its evident intent (self.n_rocks).
 PerlinGenerator (the walls of main.py:75) thresholds 2-D improved Perlin noise.  The reference gets the
@@ -144,7 +144,10 @@ class PerlinGenerator:  # generator/map_generators.py:9-25
 
 class EnvironmentGenerator:  # generator/environment_generator.py:19-106
     def __init__(self, w, h, n_ants, n_pheromones, n_rocks, food_generator, walls_generator, max_steps,
-                 seed=None, n_envs=1):
+                 seed=None, n_envs=1, env_id_base=0, n_envs_total=0):
+        # env_id_base / n_envs_total (extension, AntsCfg.env_id_base): this generator builds envs [env_id_base,
+        # env_id_base + n_envs) of a sharded batch of n_envs_total — global env g is drawn with seed + g on any shard
+        self.env_id_base, self.n_envs_total = int(env_id_base), int(n_envs_total)
         self.w, self.h, self.n_ants = w, h, n_ants
         self.n_pheromones, self.n_rocks = n_pheromones, n_rocks
         self.food_generator, self.walls_generator = food_generator, walls_generator
@@ -191,7 +194,7 @@ class EnvironmentGenerator:  # generator/environment_generator.py:19-106
 
     def draw(self):
         """Initial state of the whole batch as env-major numpy arrays (AntsInit layout)."""
-        per = [self._draw_one(None if self.seed is None else self.seed + e) for e in range(self.n_envs)]
+        per = [self._draw_one(None if self.seed is None else self.seed + self.env_id_base + e) for e in range(self.n_envs)]
         init = {k: np.stack([p[k] for p in per]) for k in per[0]}
         if self.n_rocks == 0:
             init.pop("rocks")
@@ -221,7 +224,8 @@ class EnvironmentGenerator:  # generator/environment_generator.py:19-106
         rl_api.register_ants(ants)                                         # :101
         rl_api._pending = (dict(n_envs=self.n_envs, n_ants=self.n_ants, w=self.w, h=self.h,
                                 n_phero=self.n_pheromones, n_rocks=self.n_rocks, max_time=self.max_steps,
-                                max_hold=5.0, phero_max_val=255.0, deposit_strength=1.0), init)
+                                max_hold=5.0, phero_max_val=255.0, deposit_strength=1.0,
+                                env_id_base=self.env_id_base, n_envs_total=self.n_envs_total), init)
         mask = None if self.perception_mask is None else np.asarray(self.perception_mask)
         radius = mask.shape[0] // 2 if mask is not None else 3
         rl_api.setup_perception(radius, perceived, mask, self.perception_shift)  # :102-105
@@ -243,7 +247,7 @@ class DeviceEnvironmentGenerator(EnvironmentGenerator):
     host once per env, uploaded as bitmaps).
     auto_reset=True regenerates every env (the next seeds) right after the update of the step that reported done.
     Two limits of auto_reset with reference_streams=True (include/antsrl.h, antsrl_generate): (1) episode k draws env e
-    from seed + k * n_envs + e, and np.random.seed takes 32 bits — once (seed + n_envs) * 5 would pass 2^32 the step that
+    from seed + k * n_envs_total + env_id_base + e, and np.random.seed takes 32 bits — once (seed + env_id_base + n_envs) * 5 would pass 2^32 the step that
     triggers the reset raises (ANTSRL_E_INVALID) instead of wrapping onto an earlier episode's seed; (2) bitmaps of a
     custom walls_generator are drawn ONCE here and re-used by every later episode (the reference calls
     walls_generator.generate per episode, environment_generator.py:66): call generate() again between episodes if the
@@ -251,8 +255,9 @@ class DeviceEnvironmentGenerator(EnvironmentGenerator):
 
     def __init__(self, w, h, n_ants, n_pheromones, n_rocks, max_steps, seed=0, n_envs=1, wall_density=0.05,
                  n_food_discs=20, food_rmin=5, food_rmax=10, auto_reset=False, walls_generator=None,
-                 reference_streams=False):
-        super().__init__(w, h, n_ants, n_pheromones, n_rocks, None, walls_generator, max_steps, seed=seed, n_envs=n_envs)
+                 reference_streams=False, env_id_base=0, n_envs_total=0):
+        super().__init__(w, h, n_ants, n_pheromones, n_rocks, None, walls_generator, max_steps, seed=seed, n_envs=n_envs,
+                         env_id_base=env_id_base, n_envs_total=n_envs_total)
         rng = "reference" if reference_streams else "counter"
         self.walls_bitmaps = None
         if walls_generator is None:
@@ -285,7 +290,8 @@ class DeviceEnvironmentGenerator(EnvironmentGenerator):
         rl_api.register_ants(ants)
         rl_api._pending = (dict(n_envs=self.n_envs, n_ants=self.n_ants, w=self.w, h=self.h,
                                 n_phero=self.n_pheromones, n_rocks=self.n_rocks, max_time=self.max_steps,
-                                max_hold=5.0, phero_max_val=255.0, deposit_strength=1.0),
+                                max_hold=5.0, phero_max_val=255.0, deposit_strength=1.0,
+                                env_id_base=self.env_id_base, n_envs_total=self.n_envs_total),
                            ("device", self.gen, int(self.seed or 0), self.walls_bitmaps))
         mask = None if self.perception_mask is None else np.asarray(self.perception_mask)
         rl_api.setup_perception(mask.shape[0] // 2 if mask is not None else 3, perceived, mask, self.perception_shift)

@@ -256,7 +256,12 @@ def main():
         f3 = np.ones((3, 3)) * args.diffuse
         f3[1, 1] = 1 - 8 * args.diffuse
         extra["filt"] = f3 * (1 - 0.001)  # DIFFUSE_FILTER, pheromone.py:8-10
-    cfg = cm.make_cfg(E, W_["N"], W_["W"], W_["H"], **extra)
+    # weak scaling: every rank steps E environments of ONE batch of world * E; the rank's block carries its global env ids
+    # (AntsCfg.env_id_base), so every environment-keyed random stream — the wall jitter of this loop — is the one the
+    # unsharded batch would draw: ranks do not repeat each other's streams and sharding cannot change a result
+    env_id_base = rank * E
+    extra_id = dict(extra, env_id_base=env_id_base, n_envs_total=world * E)
+    cfg = cm.make_cfg(E, W_["N"], W_["W"], W_["H"], **extra_id)
     policy_kind = args.policy or W_.get("policy", "random")
     obs_dtype = args.obs_dtype or ("bf16" if policy_kind == "mlp" else "f32")
     env = BatchedAntsEnv(cfg, dev, obs_dtype=torch.bfloat16 if obs_dtype == "bf16" else torch.float32)
@@ -318,11 +323,28 @@ def main():
     ev_slot = {rt: i for i, rt in enumerate(timed_steps)}
 
     def barrier():
-        stepper.drain()  # the last steps' gathers belong to the timed region
+        gathered = stepper.drain()  # the last steps' gathers belong to the timed region
         torch.cuda.synchronize(dev)
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize(dev)
+        return gathered
+
+    gather_checks = 0
+
+    def check_gather(gathered):
+        """Once per timed region, outside it: the all-gathered batch holds THIS rank's reward / done of the last step in
+        the rows of its global env ids, bit for bit — the first real multi-GPU run checks itself."""
+        nonlocal gather_checks
+        if gathered is None:
+            return
+        rew_all, done_all = gathered
+        assert tuple(rew_all.shape) == (world * E, cfg.n_ants) and tuple(done_all.shape) == (world * E,), \
+            "gathered shapes %s / %s" % (tuple(rew_all.shape), tuple(done_all.shape))
+        lo = env_id_base
+        assert torch.equal(rew_all[lo:lo + E], env.reward), "rank %d: gathered reward rows [%d, %d) differ from the local tensor" % (rank, lo, lo + E)
+        assert torch.equal(done_all[lo:lo + E].to(torch.uint8), env.done), "rank %d: gathered done rows differ from the local tensor" % rank
+        gather_checks += 1
 
     # REPEATS timed regions of exactly K steps each, every one bracketed by barrier + synchronize on both
     # sides and reduced with MAX over the ranks; `value` is the MEDIAN region (SURVEY.md §8(d): median of 5),
@@ -337,14 +359,20 @@ def main():
                 env.set_timing_events([evs.ev[NEV * ev_slot[(rep, t)] + i].value for i in range(NEV)])
             one_step(step_no)
             step_no += 1
-        barrier()
+        gathered = barrier()
         el = time.perf_counter() - t0
         if dist is not None:
             tmax = torch.tensor([el], dtype=torch.float64, device=dev)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             el = float(tmax.item())
         region_s.append(el)
+        check_gather(gathered)
     elapsed = float(np.median(region_s))
+    bases = [env_id_base]
+    if dist is not None:  # every rank's first global env id, for the line: the run documents its own sharding
+        tb = torch.zeros(dist.get_world_size(), dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(tb, torch.tensor([env_id_base], dtype=torch.int64, device=dev))
+        bases = [int(v) for v in tb.tolist()]
 
     out = None
     if rank == 0:
@@ -387,6 +415,12 @@ def main():
                             traffic_source=(traffic_rec.get("_source") if traffic is not None else None),
                             algorithmic_bytes_per_launch=ab[dom] * E,
                             kernel_ms={names[k]: round(v, 4) for k, v in kern.items()})
+            # the WHOLE step against the roofline: the algorithmic bytes of every kernel the step actually launches
+            # (no sweep term with scaled units: that pass does not exist) over the measured step time
+            step_bytes = sum(ab[k] for k in kern) * E
+            roofline["step_algorithmic_bytes"] = step_bytes
+            roofline["step_achieved"] = round(step_bytes / (elapsed / K) / 1e9, 1)
+            roofline["step_frac"] = round(step_bytes / (elapsed / K) / 1e9 / HBM_PEAK_GBS, 4)
             step_traffic = [traffic_rec.get(names[k]) for k in kern]
             if traffic_rec and all(v is not None for v in step_traffic):
                 # real HBM bytes of one whole step (PMC, every kernel of the step) over the measured step time
@@ -402,18 +436,6 @@ def main():
             roofline["frac_of_measured_copy"] = round(roofline["achieved"] / copy_gbs, 4)
             roofline["guide_copy_gbs"] = GUIDE_COPY_GBS
             roofline["frac_of_guide_copy"] = round(roofline["achieved"] / GUIDE_COPY_GBS, 4)
-            # bytes the dominant kernel moves across the CU <-> L2 interface per launch (PMC: 64-byte TCP -> TCC requests;
-            # not measured in this run, like `traffic`) against the copy kernel's rate across the same interface:
-            # DESIGN.md 5.2.2 — k_perceive is bound there, not at the HBM bus
-            cpath = os.path.join(ROOT, "profiles", "cu_l2_traffic_%s.json" % args.config)
-            crec = json.load(open(cpath)) if os.path.exists(cpath) else {}
-            if crec.get(roofline.get("kernel")):
-                cb = crec[roofline["kernel"]]
-                cgbs = cb / (roofline["kernel_ms"][roofline["kernel"]] * 1e-3) / 1e9
-                roofline["cu_l2_traffic"] = cb
-                roofline["cu_l2_traffic_source"] = crec.get("_source")
-                roofline["cu_l2_gbs"] = round(cgbs, 1)
-                roofline["cu_l2_frac_of_measured_copy"] = round(cgbs / copy_gbs, 4)
         value = world * E * cfg.n_ants * K / elapsed
         out = {
             "metric": "ant-steps/sec (ants x envs x steps/s), 256^2 grid" if cfg.w == 256 else "ant-steps/sec (ants x envs x steps/s)",
@@ -423,6 +445,8 @@ def main():
             "repeats": REPEATS, "ms_per_step_regions": [round(r / K * 1e3, 5) for r in region_s],
             "ms_per_step_spread": round((max(region_s) - min(region_s)) / K * 1e3, 5),
             "rccl_ranks": (dist.get_world_size() if dist is not None else 1),
+            "env_id_base_per_rank": bases, "n_envs_total": world * E,
+            "gather_self_checks": gather_checks,  # regions whose all-gathered own-shard rows were compared with the local tensors
             "config": {"workload": W_["desc"], "episode_age_steps": args.age, "envs_per_gpu": E, "ants": cfg.n_ants, "grid": [cfg.w, cfg.h],
                        "pheromone_channels": cfg.n_phero, "rocks": cfg.n_rocks, "obs_channels": cfg.n_channels,
                        "filter_radius": cfg.filter_radius,
@@ -449,7 +473,7 @@ def main():
         # model can be checked like for like.  Outside the timed region.
         del env
         torch.cuda.empty_cache()
-        ex = dict(extra)
+        ex = dict(extra_id)
         ex["phero_mode"] = cm.PHERO_EXPLICIT_SWEEP
         cfg_x = cm.make_cfg(E, W_["N"], W_["W"], W_["H"], **ex)
         env_x = BatchedAntsEnv(cfg_x, dev)

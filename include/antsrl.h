@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define ANTSRL_ABI_VERSION 4
+#define ANTSRL_ABI_VERSION 5
 
 #define ANTSRL_MAX_CHANNELS 16
 #define ANTSRL_MAX_PSIDE 15                                      /* 2*radius+1 <= 15 */
@@ -137,10 +137,22 @@ typedef struct AntsCfg {
     double fct_explore, fct_food, fct_anthill, fct_explore_holding, fct_headinganthill;
 
     /* Walls.update jitter (walls.py:28) when no explicit draws are supplied:
-     * counter-based generator keyed on (rng_seed, env, timestep, ant). */
+     * counter-based generator keyed on (rng_seed, GLOBAL env id, timestep, ant). */
     uint64_t rng_seed;
 
     int32_t act_path; /* ANTSRL_ACT_* (no reference counterpart) */
+
+    /* GLOBAL ENVIRONMENT IDENTITY (ABI 5).  The reference seeds every environment by itself
+     * (generator/environment_generator.py:53-55; the np.random stream Walls.update draws from, walls.py:28, belongs
+     * to that environment), so an environment's trajectory must not depend on which handle / rank / batch position
+     * it lands on.  Environment e of this handle IS global environment env_id_base + e: every random stream the
+     * library keys on an environment — the built-in wall jitter, both generators of antsrl_generate — takes the
+     * global id.  A handle over envs [lo, hi) of a sharded batch with env_id_base = lo reproduces rows lo:hi of the
+     * whole-batch handle bit for bit (tests/test_gpu_shard_identity.py).  n_envs_total: environments in the whole
+     * (sharded) batch, the stride between the auto-reset episodes of ANTSRL_RNG_REFERENCE (env g of episode k draws
+     * from episode_seed + k * n_envs_total + g); 0 = env_id_base + n_envs. */
+    int32_t env_id_base;
+    int32_t n_envs_total;
     int32_t _pad1;
 } AntsCfg;
 
@@ -171,16 +183,17 @@ typedef struct AntsInit {
                                     walls_generator.generate(w, h) returned; cleared on the anthill area
                                     like environment_generator.py:66-67 */
 /* random streams of the device generator */
-#define ANTSRL_RNG_COUNTER 0     /* counter-based, keyed on (episode_seed, env, item): same distributions as the
-                                    reference's generator, different maps (the oracle restates it) */
-#define ANTSRL_RNG_REFERENCE 1   /* the reference's own streams: env e is drawn like EnvironmentGenerator(seed =
-                                    episode_seed + e).generate — random.seed(seed) / np.random.seed(seed * 5)
+#define ANTSRL_RNG_COUNTER 0     /* counter-based, keyed on (episode_seed, global env id, item): same distributions as
+                                    the reference's generator, different maps (the oracle restates it) */
+#define ANTSRL_RNG_REFERENCE 1   /* the reference's own streams: env e (global id g = AntsCfg.env_id_base + e) is drawn
+                                    like EnvironmentGenerator(seed = episode_seed + g).generate — random.seed(seed) / np.random.seed(seed * 5)
                                     (environment_generator.py:53-55), i.e. two MT19937 generators per env with
                                     Python's and numpy's seeding and 53-bit doubles, consumed in the reference's order
                                     (anthill :60-63, PerlinGenerator's two randints map_generators.py:19-20,
                                     CirclesGenerator :37-39, rocks :77-85, ants :87-91, Ants.seed ants.py:41): equal
                                     seeds give the reference's anthill, food discs, ants and seeds bit for bit.
-                                    Walls: ANTSRL_WALLS_PERLIN or ANTSRL_WALLS_INPUT.  (episode_seed + E) * 5 < 2^32. */
+                                    Walls: ANTSRL_WALLS_PERLIN or ANTSRL_WALLS_INPUT.
+                                    (episode_seed + env_id_base + E) * 5 < 2^32. */
 typedef struct AntsGen {
     double wall_density;   /* Bernoulli: probability of a wall cell; Perlin: PerlinGenerator.density (threshold) */
     int32_t n_food_discs;  /* CirclesGenerator.n_circles, main.py:74 uses 20 (<= ANTSRL_MAX_FOOD_DISCS) */
@@ -256,14 +269,16 @@ int antsrl_reset(AntsHandle *h, const AntsInit *init, void *stream);
  * draws (generator/environment_generator.py:52-106) — anthill in the central half, walls cleared on
  * the anthill, food discs zeroed on walls, rocks in the generator's band, ants in a disc of 0.8 r
  * around the anthill — and loads it exactly like antsrl_reset.  gen->rng_kind picks the random source:
- *   ANTSRL_RNG_COUNTER    a counter-based generator keyed on (episode_seed, env, item): the reference's
+ *   ANTSRL_RNG_COUNTER    a counter-based generator keyed on (episode_seed, global env id, item): the reference's
  *                         distributions, NOT its maps (the oracle's oracle_generate restates this generator);
  *   ANTSRL_RNG_REFERENCE  the reference's own MT19937 streams (Python's `random` and `np.random`, seeded like
- *                         environment_generator.py:53-55): env e equals EnvironmentGenerator(seed = episode_seed + e)
+ *                         environment_generator.py:53-55): env e equals EnvironmentGenerator(seed = episode_seed +
+ *                         env_id_base + e)
  *                         — anthill, food discs, rocks, ants and per-ant seeds bit for bit (see ANTSRL_RNG_* above).
  * With gen->auto_reset the handle keeps `gen` and re-runs it after every finished episode: with episode_seed + 1,
- * + 2, ... (ANTSRL_RNG_COUNTER) or E seeds further each time (ANTSRL_RNG_REFERENCE: env e of episode k takes seed
- * episode_seed + k * E + e).  Two limits of that mode: np.random.seed takes 32 bits, so (seed + E) * 5 must stay
+ * + 2, ... (ANTSRL_RNG_COUNTER) or AntsCfg.n_envs_total seeds further each time (ANTSRL_RNG_REFERENCE: global env g of
+ * episode k takes seed episode_seed + k * n_envs_total + g, whatever the sharding).  Two limits of that mode:
+ * np.random.seed takes 32 bits, so (seed + env_id_base + E) * 5 must stay
  * below 2^32 — checked again at every auto-reset, which returns ANTSRL_E_INVALID instead of wrapping; and with
  * ANTSRL_WALLS_INPUT every episode re-uses the bitmaps of the first call (the reference calls walls_generator.generate
  * per episode: pass fresh bitmaps through antsrl_generate between episodes if the walls are to change). */
@@ -292,7 +307,7 @@ int antsrl_observe(AntsHandle *h, float *obs, float *agent_state, float *reward,
  *   wall_jitter  double [E][N] or NULL.  When given, entry k of env e is the k-th
  *   value np.random.random(k) would have returned in Walls.update (walls.py:28):
  *   the k-th colliding ant, in ant-index order, consumes it.  NULL = built-in
- *   counter-based generator (AntsCfg.rng_seed).
+ *   counter-based generator keyed on (AntsCfg.rng_seed, AntsCfg.env_id_base + e, timestep, ant).
  * DEFERRED UPDATE.  With wall_jitter == NULL on the cell-meta path (scaled pheromone units, <= 1024 ants,
  * ANTSRL_Q_DEFERRED_UPDATE) the call does the update's bookkeeping and returns without enqueuing its kernel: the
  * next antsrl_step / antsrl_step_update runs it in the same launch as its move (k_update_move: the move re-reads

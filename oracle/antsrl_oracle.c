@@ -163,29 +163,30 @@ void oracle_generate_init(const AntsCfg *c, const AntsGen *g, uint64_t seed, dou
     const int W = c->w, H = c->h, N = c->n_ants, R = c->n_rocks, m = W < H ? W : H;
     const size_t G = (size_t)W * H;
     for (int e = 0; e < c->n_envs; ++e) {
-        const long ax = (int)(gen_u01(seed, e, GEN_ANTHILL, 0) * W * 0.5 + W * 0.25);   /* :61 */
-        const long ay = (int)(gen_u01(seed, e, GEN_ANTHILL, 1) * H * 0.5 + H * 0.25);   /* :62 */
-        const long ar = (int)(gen_u01(seed, e, GEN_ANTHILL, 2) * m * 0.05 + m * 0.05);  /* :63 */
+        const uint32_t ge = (uint32_t)c->env_id_base + (uint32_t)e; /* the env's GLOBAL id keys its streams (AntsCfg.env_id_base) */
+        const long ax = (int)(gen_u01(seed, ge, GEN_ANTHILL, 0) * W * 0.5 + W * 0.25);   /* :61 */
+        const long ay = (int)(gen_u01(seed, ge, GEN_ANTHILL, 1) * H * 0.5 + H * 0.25);   /* :62 */
+        const long ar = (int)(gen_u01(seed, ge, GEN_ANTHILL, 2) * m * 0.05 + m * 0.05);  /* :63 */
         xyr[3 * e] = (int32_t)ax; xyr[3 * e + 1] = (int32_t)ay; xyr[3 * e + 2] = (int32_t)ar;
         for (int q = 0; q < R; ++q) {                                                   /* :77-85 */
             double *rk = rocks + ((size_t)e * R + q) * 4;
-            rk[0] = gen_u01(seed, e, GEN_ROCKS, 4 * q + 0) * (W * 0.75) + W * 0.25;
-            rk[1] = gen_u01(seed, e, GEN_ROCKS, 4 * q + 1) * (H * 0.25) + H * 0.25;
-            rk[2] = gen_u01(seed, e, GEN_ROCKS, 4 * q + 2) * 5 + 5;
-            rk[3] = gen_u01(seed, e, GEN_ROCKS, 4 * q + 3) * 50 + 50;
+            rk[0] = gen_u01(seed, ge, GEN_ROCKS, 4 * q + 0) * (W * 0.75) + W * 0.25;
+            rk[1] = gen_u01(seed, ge, GEN_ROCKS, 4 * q + 1) * (H * 0.25) + H * 0.25;
+            rk[2] = gen_u01(seed, ge, GEN_ROCKS, 4 * q + 2) * 5 + 5;
+            rk[3] = gen_u01(seed, ge, GEN_ROCKS, 4 * q + 3) * 50 + 50;
         }
         long discs[ANTSRL_MAX_FOOD_DISCS][3];
         for (int d = 0; d < g->n_food_discs; ++d) {                                     /* map_generators.py:37-40 */
-            long rad = (int)(gen_u01(seed, e, GEN_FOOD, 3 * d + 0) * (g->food_rmax - g->food_rmin) + g->food_rmin);
+            long rad = (int)(gen_u01(seed, ge, GEN_FOOD, 3 * d + 0) * (g->food_rmax - g->food_rmin) + g->food_rmin);
             const long cap = (m - 1) / 2;
             if (rad > cap) rad = cap;
             discs[d][0] = rad;
-            discs[d][1] = (int)(gen_u01(seed, e, GEN_FOOD, 3 * d + 1) * (W - 2 * rad) + rad);
-            discs[d][2] = (int)(gen_u01(seed, e, GEN_FOOD, 3 * d + 2) * (H - 2 * rad) + rad);
+            discs[d][1] = (int)(gen_u01(seed, ge, GEN_FOOD, 3 * d + 1) * (W - 2 * rad) + rad);
+            discs[d][2] = (int)(gen_u01(seed, ge, GEN_FOOD, 3 * d + 2) * (H - 2 * rad) + rad);
         }
         /* PerlinGenerator.generate draws random.randint(-10000, 10000) twice, map_generators.py:19-20 */
-        const long pox = (long)(gen_u01(seed, e, GEN_WALL_OFFSET, 0) * 20001.0) - 10000;
-        const long poy = (long)(gen_u01(seed, e, GEN_WALL_OFFSET, 1) * 20001.0) - 10000;
+        const long pox = (long)(gen_u01(seed, ge, GEN_WALL_OFFSET, 0) * 20001.0) - 10000;
+        const long poy = (long)(gen_u01(seed, ge, GEN_WALL_OFFSET, 1) * 20001.0) - 10000;
         for (long x = 0; x < W; ++x)
             for (long y = 0; y < H; ++y) {
                 const size_t cell = (size_t)x * H + y;
@@ -196,7 +197,7 @@ void oracle_generate_init(const AntsCfg *c, const AntsGen *g, uint64_t seed, dou
                                                    (float)((double)(y + poy) / g->perlin_scale), g->perlin_octaves,
                                                    (float)g->perlin_persistence, (float)g->perlin_lacunarity) > g->wall_density;
                 else
-                    wall = !area && gen_u01(seed, e, GEN_WALLS, (uint32_t)cell) < g->wall_density;
+                    wall = !area && gen_u01(seed, ge, GEN_WALLS, (uint32_t)cell) < g->wall_density;
                 int fd = 0;
                 for (int d = 0; d < g->n_food_discs; ++d) {
                     const long dx = discs[d][1] - x, dy = discs[d][2] - y;
@@ -206,13 +207,13 @@ void oracle_generate_init(const AntsCfg *c, const AntsGen *g, uint64_t seed, dou
                 food[e * G + cell] = (fd && !wall) ? 1.0f : 0.0f;                        /* :71-72 */
             }
         for (int a = 0; a < N; ++a) {                                                    /* :87-93 */
-            const double ang = gen_u01(seed, e, GEN_ANT_ANGLE, a) * 2 * PI_D;
-            const double dist = gen_u01(seed, e, GEN_ANT_DIST, a) * (double)ar * 0.8;
+            const double ang = gen_u01(seed, ge, GEN_ANT_ANGLE, a) * 2 * PI_D;
+            const double dist = gen_u01(seed, ge, GEN_ANT_DIST, a) * (double)ar * 0.8;
             double *o = ants_xyt + ((size_t)e * N + a) * 3;
             o[0] = cos(ang) * dist + (double)ax;
             o[1] = sin(ang) * dist + (double)ay;
-            o[2] = gen_u01(seed, e, GEN_ANT_THETA, a) * 2 * PI_D;
-            seed_out[(size_t)e * N + a] = (double)(float)gen_u01(seed, e, GEN_ANT_SEED, a);
+            o[2] = gen_u01(seed, ge, GEN_ANT_THETA, a) * 2 * PI_D;
+            seed_out[(size_t)e * N + a] = (double)(float)gen_u01(seed, ge, GEN_ANT_SEED, a);
         }
     }
 }
@@ -523,7 +524,7 @@ static int env_update(const AntsCfg *c, EnvView *v, int env_index, const double 
         if (v->walls[cell]) {                             /* :26 */
             v->x[i] = v->prev_x[i]; v->y[i] = v->prev_y[i]; /* :27 */
             double u = jitter ? jitter[hits]
-                              : oracle_jitter_u01(c->rng_seed, (uint32_t)env_index,
+                              : oracle_jitter_u01(c->rng_seed, (uint32_t)c->env_id_base + (uint32_t)env_index, /* the env's GLOBAL id */
                                                   (uint32_t)*v->timestep, (uint32_t)i);
             v->theta[i] += u - 0.5;                       /* :28 (theta not re-wrapped) */
             ++hits;

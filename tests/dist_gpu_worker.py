@@ -1,8 +1,9 @@
-"""Worker of tests/test_gpu_dist.py: one rank per GPU under torch.distributed.run (backend "nccl" = RCCL).
+"""Worker of tests/test_a_gpu_dist.py: one rank per GPU under torch.distributed.run (backend "nccl" = RCCL).
 
 Every rank steps ITS contiguous block of a global batch with `ShardedStepper` (the loop bench.py --gpus N runs), in
 `staged` and in `zero_copy` mode, and also steps the WHOLE batch alone on its own GPU: the gathered reward / done of every
-step must equal the single-rank result bit for bit (environments are independent, so sharding must not change a value).
+step must equal the single-rank result bit for bit (environments are independent and every shard carries its global
+environment ids — AntsCfg.env_id_base — so sharding must not change a value, the library's own wall jitter included).
 Prints "DIST_GPU_OK <rank>" and exits 0 on success."""
 import os
 import sys
@@ -20,7 +21,7 @@ def main():
     dist.init_process_group("nccl", device_id=dev)
     from antsrl_amd import config as cm
     from antsrl_amd.batched import BatchedAntsEnv
-    from antsrl_amd.dist import RewardGather, ShardedStepper, shard_range
+    from antsrl_amd.dist import RewardGather, ShardedStepper, shard_cfg, shard_range
     from antsrl_amd.synth import synth_init
     assert dist.get_world_size() == world
     E, N, steps = 6 * world + 1, 96, 8  # (ragged: the blocks differ by one environment)
@@ -32,15 +33,17 @@ def main():
     # the whole batch on this GPU alone: the reference every sharded run must reproduce
     cfg_all = cm.make_cfg(E, N, 64, 64, n_rocks=2, deposit_strength=256.0)
     ref = BatchedAntsEnv(cfg_all, dev)
-    ref.reset(synth_init(cfg_all, seed=9, n_food_discs=4, food_rmin=2, food_rmax=4))
+    ref.reset(synth_init(cfg_all, seed=9, wall_density=0.08, n_food_discs=4, food_rmin=2, food_rmax=4))
     want = []
     for t in range(steps):
         ref.step_update(rot[t], ph[t], None)
         want.append((ref.reward.clone(), ref.done.clone()))
     for mode in ("staged", "zero_copy"):
-        cfg = cm.make_cfg(hi - lo, N, 64, 64, n_rocks=2, deposit_strength=256.0)
+        # the shard knows its place in the batch: env_id_base = lo keys the library's wall jitter on the GLOBAL env id
+        cfg, lo_c, hi_c = shard_cfg(E, rank, world, N, 64, 64, n_rocks=2, deposit_strength=256.0)
+        assert (lo_c, hi_c) == (lo, hi) and cfg.env_id_base == lo and cfg.n_envs_total == E
         env = BatchedAntsEnv(cfg, dev)
-        env.reset(synth_init(cfg, seed=9, env_offset=lo, n_food_discs=4, food_rmin=2, food_rmax=4))
+        env.reset(synth_init(cfg, seed=9, wall_density=0.08, env_offset=lo, n_food_discs=4, food_rmin=2, food_rmax=4))
         gather = RewardGather(E, N, dev)
         stepper = ShardedStepper(env, gather, mode)
         for t in range(steps):

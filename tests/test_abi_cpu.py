@@ -35,7 +35,7 @@ def test_header_symbols_are_exported(lib):
 
 
 def test_layout_and_version(lib):
-    assert lib.antsrl_abi_version() == 4
+    assert lib.antsrl_abi_version() == 5
     assert lib.antsrl_cfg_size() == C.sizeof(AntsCfg)
 
 
@@ -64,6 +64,18 @@ def test_workspace_bytes_and_validation(lib):
     bad = cfg.copy()
     bad.abi_version = 7
     assert lib.antsrl_workspace_bytes(C.byref(bad), C.byref(n)) == -1
+
+
+def test_env_identity_fields_are_validated(lib):
+    """AntsCfg.env_id_base / n_envs_total (ABI 5): a negative base, a base past 31 bits and a total smaller than the
+    shard's own end are refused by the host-side validation."""
+    n = C.c_size_t()
+    ok = make_cfg(8, 16, 32, 32, env_id_base=1016, n_envs_total=1024)
+    assert lib.antsrl_workspace_bytes(C.byref(ok), C.byref(n)) == 0
+    for base, total, msg in ((-1, 0, b"env_id_base"), (0x7fffffff - 3, 0, b"env_id_base"), (1016, 1023, b"n_envs_total")):
+        bad = make_cfg(8, 16, 32, 32, env_id_base=base, n_envs_total=total)
+        assert lib.antsrl_workspace_bytes(C.byref(bad), C.byref(n)) == -1
+        assert msg in lib.antsrl_last_error()
 
 
 def test_create_rejects_bad_workspace(lib):

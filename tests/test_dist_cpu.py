@@ -144,6 +144,80 @@ def test_bench_step_loop_two_ranks(mode):
             np.testing.assert_array_equal(d, np.array([(e + t) % 2 for e in range(E)], np.uint8))
 
 
+class _OracleEnv:
+    """Stand-in for BatchedAntsEnv on CPU with REAL arithmetic: the oracle (test infrastructure) steps this rank's block
+    with the library's specification of the built-in wall jitter, keyed on the GLOBAL environment id the shard's AntsCfg
+    carries (env_id_base) — what the HIP kernels do on a GPU (tests/test_gpu_shard_identity.py)."""
+
+    def __init__(self, cfg, init):
+        from oracle.oracle import Oracle
+        self.orc = Oracle(cfg, init)
+        self.reward = torch.zeros((cfg.n_envs, cfg.n_ants), dtype=torch.float32)
+        self.done = torch.zeros((cfg.n_envs,), dtype=torch.uint8)
+
+    def step_update(self, rot, ph):
+        _, _, rew, done = self.orc.step(rot, ph, want_obs=False)
+        self.orc.update(None)  # built-in jitter
+        self.reward.copy_(torch.from_numpy(rew.astype(np.float32)))
+        self.done.copy_(torch.from_numpy(done))
+
+
+def _identity_worker(rank, world, port, E, N, mode, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from antsrl_amd.dist import ShardedStepper, shard_cfg
+        from antsrl_amd.synth import random_actions
+        cfg, lo, hi = shard_cfg(E, rank, world, N, 32, 32, deposit_strength=256.0, max_time=4)
+        assert cfg.env_id_base == lo and cfg.n_envs == hi - lo and cfg.n_envs_total == E
+        init = synth_init(cfg, seed=50, env_offset=lo, wall_density=0.2, n_food_discs=3, food_rmin=2, food_rmax=4)
+        rot, ph = random_actions(make_cfg(E, N, 32, 32), 6, seed=2)  # the whole batch's actions, sliced per rank
+        env = _OracleEnv(cfg, init)
+        st = ShardedStepper(env, RewardGather(E, N, "cpu"), mode)
+        seen = []
+        for t in range(6):
+            st.step(t, lambda: env.step_update(rot[t][lo:hi], ph[t][lo:hi]))
+            r, d = st.drain()
+            seen.append((r.clone().numpy(), d.clone().numpy()))
+        q.put((rank, seen, env.orc.theta.copy()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,E,mode", [(2, 5, "staged"), (3, 7, "zero_copy")])
+def test_sharded_run_equals_the_single_process_batch(world, E, mode):
+    """world gloo ranks step their blocks of one batch (shard_cfg: env_id_base = the block's first global id) with the
+    library's OWN wall jitter and all-gather reward / done every step: every rank sees exactly what one process stepping
+    the whole batch computes — sharding does not change a result (north_star: identical seeds, identical results)."""
+    from antsrl_amd.synth import random_actions
+    from oracle.oracle import Oracle
+    N = 24
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_identity_worker, args=(r, world, port, E, N, mode, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=180) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    cfg = make_cfg(E, N, 32, 32, deposit_strength=256.0, max_time=4)
+    whole = Oracle(cfg, synth_init(cfg, seed=50, wall_density=0.2, n_food_discs=3, food_rmin=2, food_rmax=4))
+    theta0 = whole.theta.copy()
+    rot, ph = random_actions(cfg, 6, seed=2)
+    for t in range(6):
+        _, _, rew, done = whole.step(rot[t], ph[t], want_obs=False)
+        whole.update(None)
+        for _, seen, _ in res:
+            np.testing.assert_array_equal(seen[t][0], rew.astype(np.float32), err_msg="step %d" % t)
+            np.testing.assert_array_equal(seen[t][1], done, err_msg="step %d" % t)
+        assert done.all() == (t == 3)  # RL_api.py:200: done exactly when timestep == max_time
+    np.testing.assert_array_equal(np.concatenate([r[2] for r in res]), whole.theta)  # the jitter itself, bit for bit
+    assert (np.abs(whole.theta - theta0) > 0).any()
+
+
 def test_shard_range_partitions():
     for E in (1, 7, 8, 1024, 8192):
         for world in (1, 2, 3, 8):
