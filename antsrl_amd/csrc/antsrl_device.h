@@ -48,6 +48,18 @@
 #else
 #define PROF_ENV(name) ((const char *)nullptr)
 #endif
+// Compile-time ablations (bit masks, results WRONG by design: antsrl_perceive.hip, antsrl_update_one.h) and the wave
+// time-line trace of k_perceive exist in variant builds of the profiling library only — a product build with any of them
+// set does not compile.
+#ifndef PRC_ABL
+#define PRC_ABL 0
+#endif
+#ifndef UM_ABL
+#define UM_ABL 0
+#endif
+#if !defined(ANTSRL_PROFILING) && (PRC_ABL != 0 || UM_ABL != 0 || defined(PRC_TRACE))
+#error "PRC_ABL / UM_ABL / PRC_TRACE are profiling switches: build them with -DANTSRL_PROFILING (python -m antsrl_amd.build --variant NAME -D...)"
+#endif
 
 struct __align__(16) AntFrame { double cx, cy, ct, st; }; // perception centre, cos/sin(theta + pi/2)
 // k_update_move: what the update hands to the move of the same ant in registers (x, y after the update = the new `prev`, theta)

@@ -32,12 +32,7 @@ __host__ __device__ inline FlushPlanF32 flush_plan_f32(uint32_t lane, uint32_t m
 {
     FlushPlanF32 f;
     const uint32_t j_lo = (mis + 3) >> 2, j_hi = (mis + rowp) >> 2; // interior float4s [j_lo, j_hi)
-#ifdef FLUSH_NO_ALIGN // variant (A/B): the 16-byte stores start at the run's first piece, whatever its phase against the 128-byte lines
-    const uint32_t head = 0u;
-    (void)line_phase;
-#else
     const uint32_t head = (j_hi - j_lo >= 72u) ? ((8u - ((line_phase + j_lo) & 7u)) & 7u) : 0u;
-#endif
     const uint32_t last = j_hi - 1;
     const uint32_t a = j_lo + head + lane, b = j_lo + head + 64u + lane;
     const uint32_t c = lane < head ? j_lo + lane : j_lo + 128u + lane;
@@ -70,44 +65,5 @@ __host__ __device__ inline FlushPlanB16 flush_plan_b16(uint32_t lane, uint32_t m
     return f;
 }
 
-// ---------------------------------------------------------------------------------------------------
-// Whole-line copy-out with carry (k_perceive).  A wave owns a CONTIGUOUS run of observation rows; its LDS
-// image mirrors the destination modulo one 128-byte line: image element i <-> global element line_base + i,
-// line_base 128-byte aligned.  After a group's rows are staged behind the `carry` elements left over from
-// the previous group, every WHOLE line of the image leaves as 16-byte streaming stores (every store
-// instruction covers whole aligned lines: partial-line nt stores cost the memory side a read-modify-write —
-// 3.1-3.8 TB/s against 4.9 for whole lines, profiles/r01/store_policy_probe.txt), the remainder (< one line)
-// moves to the front of the image and waits for the next group.  Only the two ends of the run are partial:
-// the head (first flush: the line is shared with the previous run) starts at the first 16-byte piece that is
-// wholly ours, the <= VEC-1 elements in front of it and the final carry leave as element-wide stores.
-// LINE = elements per 128 bytes (32 float32 / 64 bfloat16), VEC = elements per 16 bytes (4 / 8).
-// Precondition: rowp >= LINE (so that every flush has at least one whole line).
-struct LineFlush {
-    uint32_t jstart; // first 16-byte piece of the image to store
-    uint32_t n16;    // pieces [jstart, n16) leave
-    uint32_t nl;     // whole lines flushed (line_base advances by nl * LINE elements)
-    uint32_t left;   // elements [nl * LINE, nl * LINE + left) move to the front: the next carry
-    uint32_t head;   // first flush: elements [carry, carry + head) in front of piece jstart leave element-wide
-};
-
-__host__ __device__ inline LineFlush line_flush(uint32_t carry, uint32_t rowp, bool first, uint32_t LINE, uint32_t VEC)
-{
-    LineFlush f;
-    const uint32_t total = carry + rowp;
-    f.nl = total / LINE;
-    f.n16 = f.nl * (LINE / VEC);
-    f.left = total - f.nl * LINE;
-    f.jstart = first ? (carry + VEC - 1) / VEC : 0u;
-    f.head = first ? f.jstart * VEC - carry : 0u;
-    return f;
-}
-
-// 16-byte piece that lane `lane` stores in the k-th store instruction of a flush (k compile-time, 0-based).
-// A lane with nothing left repeats a piece it (or another lane) stores anyway: same address, same data.
-__host__ __device__ inline uint32_t line_piece(uint32_t lane, uint32_t k, const LineFlush &f)
-{
-    uint32_t j = f.jstart + lane + 64u * k;
-    if (k >= 1 && j >= f.n16) j -= 64u;
-    if (k >= 2 && j >= f.n16) j -= 64u;
-    return j < f.n16 ? j : f.n16 - 1u;
-}
+// (The whole-line copy-out with a carry — LineFlush / line_flush / line_piece, round 2 — lost to this plan inside the full
+// kernel at every stage and left the tree in round 4: profiles/r04/perceive_cleanup.patch.)

@@ -20,12 +20,15 @@
 #include "antsrl_update_one.h"
 
 #define PRC_UNROLL 2 // ants per group (their gathers are issued together, their rows leave together)
-#ifndef PRC_DEPTH
-// Groups whose gathers are in flight ahead of the group being consumed.  2 (shipped): same-box A/B, k_perceive ms, depth 1 /
-// 2 / 3 (3 = all four groups of a run gathered up front): c3 0.2274 / 0.2211 / 0.2284, c4 0.518 / 0.484 / 0.480, c5 0.0760 /
-// 0.0749 / 0.0805, c2 0.0271 / 0.0268 / 0.0271 (profiles/r03/depth_ab.txt).
-#define PRC_DEPTH 2
-#endif
+// The gathers of TWO groups are in flight ahead of the group being consumed (same-box A/B of one / two / all four groups
+// ahead, k_perceive ms: c3 0.2274 / 0.2211 / 0.2284, c4 0.518 / 0.484 / 0.480, c5 0.0760 / 0.0749 / 0.0805 —
+// profiles/r03/depth_ab.txt; the other two forms are in profiles/r04/perceive_cleanup.patch).
+
+// Compile-time ablations for profiles/ (results WRONG by design): bit masks, variant builds of the PROFILING library only
+// (`python -m antsrl_amd.build --variant NAME -DPRC_ABL=3`); antsrl_device.h refuses them in a product build.
+//   PRC_ABL  1: no record gathers (every lane reads one L1-resident line)   2: no observation stores   4: no explored marks
+//   UM_ABL   1: no food read   2: no presence stamp   4: no deposit read-modify-write      (k_update_move / k_move)
+constexpr bool abl_gather = (PRC_ABL & 1) != 0, abl_store = (PRC_ABL & 2) != 0, abl_mark = (PRC_ABL & 4) != 0;
 
 #define PLAYOUT_DEFAULT 1       // [Ants, Phero0, Phero1, Anthill, Walls, Food]   (generator order)
 #define PLAYOUT_DEFAULT_ROCKS 2 // ... + [CircleObstacles]
@@ -70,20 +73,16 @@ __device__ __forceinline__ void move_body(const KP &p, const int e, const int8_t
         if (fw) {
             h_x = fw->x; h_y = fw->y; h_th = fw->th;
         } else {
-            h_x = ST_LD(p.s.x[a1]); h_y = ST_LD(p.s.y[a1]); h_th = ST_LD(p.s.theta[a1]);
+            h_x = p.s.x[a1]; h_y = p.s.y[a1]; h_th = p.s.theta[a1];
         }
-        h_hold = ST_LD(p.s.holding[a1]);
+        h_hold = p.s.holding[a1];
         if (do_step) {
             const double ppx = fw ? fw->x : STP_LD(p.s.prev_x[a1]), ppy = fw ? fw->y : STP_LD(p.s.prev_y[a1]);
             h_m = STP_LD(p.s.mandibles[a1]);
             if (rotation) h_rot = STP_LD(rotation[a1]);
             if (phero_act) h_pa = STP_LD(phero_act[a1]);
             h_cprev = rec_xy(p, (int)ppx, (int)ppy); // the RECORD of the previous cell (hash key, food, dirty list)
-#ifndef UM_ABL_NO_FOOD // (ablation, variant build: the scattered food read)
-            h_q = food[h_cprev]; // food is first written in phase 1b
-#else
-            h_q = 0.0f;
-#endif
+            h_q = (UM_ABL & 1) ? 0.0f : food[h_cprev]; // food is first written in phase 1b
         }
     }
     if (do_step)
@@ -129,7 +128,7 @@ __device__ __forceinline__ void move_body(const KP &p, const int e, const int8_t
             const float taken = fminf((float)p.max_hold, fmaxf(0.0f, q)) * (float)closing; // :111
             const float dropped = hold * (float)opening;                                    // :114
             h_hold = hold + (taken - dropped);                                              // :117
-            ST_ST(p.s.holding[eN + i], h_hold);
+            p.s.holding[eN + i] = h_hold;
             STP_ST(p.s.mandibles[eN + i], (uint8_t)m);                                            // :107
             cprevs[i] = cprev;
             tmp_q[i] = q;
@@ -177,19 +176,15 @@ __device__ __forceinline__ void move_body(const KP &p, const int e, const int8_t
             if (fwd < 0) fwd *= p.backward;
             x = warp_coord(x + cs * fwd, (double)W);
             y = warp_coord(y + sn * fwd, (double)H);
-            ST_ST(p.s.x[eN + i], x);
-            ST_ST(p.s.y[eN + i], y);
-            ST_ST(p.s.theta[eN + i], th);
+            p.s.x[eN + i] = x;
+            p.s.y[eN + i] = y;
+            p.s.theta[eN + i] = th;
         }
         // presence map, RL_api.py:137-141 (0/1, not a count): this observation's number into the cell's stamp
         const uint32_t cell = rec_xy(p, wrap_index((int)x, W), wrap_index((int)y, H));
         // (a plain store: as an nt store k_update_move gains 1 us and k_perceive, whose gathers then miss the line, loses 4:
         //  profiles/r03/ntstamp_ab.txt)
-#ifndef UM_ABL_NO_STAMP // (ablation, variant build: what does the scattered 2-byte store cost?)
-        pres[(size_t)cell * FS2] = (uint16_t)seq;
-#else
-        if (cell == 0xFFFFFFFFu) pres[0] = (uint16_t)seq;
-#endif
+        if (!(UM_ABL & 2) || cell == 0xFFFFFFFFu) pres[(size_t)cell * FS2] = (uint16_t)seq;
     }
 }
 
@@ -215,16 +210,10 @@ k_update_move(const KP p, const int out_buf, const double g_dep, const double in
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const int e = env_of_block(blockIdx.x, p.E, seq);
-#ifndef UM_NO_FORWARD
     UmFwd fw = {0.0, 0.0, 0.0};
     update_one_body<C>(p, e, nullptr, out_buf, smem, g_dep, inv_g_dep, &fw);
     __syncthreads(); // the update's global writes are visible to the whole workgroup; its LDS is dead
     move_body<C>(p, e, rotation, phero_act, done, 1, seq, smem, &fw);
-#else
-    update_one_body<C>(p, e, nullptr, out_buf, smem, g_dep, inv_g_dep);
-    __syncthreads(); // the update's global writes are visible to the whole workgroup; its LDS is dead
-    move_body<C>(p, e, rotation, phero_act, done, 1, seq, smem);
-#endif
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -257,21 +246,14 @@ __host__ __device__ __forceinline__ PrcOff prc_offsets(int run, int PP, int K, i
 // k-step's 5-dword read can reach past them
 __host__ __device__ __forceinline__ uint32_t prc_policy_img_elems(int row) { return (uint32_t)((32 * row + 8 + 32 + 7) / 8 * 8); }
 
-#ifndef PRC_TPB
 #define PRC_TPB 256 // 4 waves per workgroup; 64 / 128 measured no better (profiles/r02/prc_tpb.txt)
-#endif
 
-// Which ant of the workgroup's tile the j-th ant of wave `w` is.  PRC_INTERLEAVE_WAVES (variant build): the waves take
-// alternating 2-ant groups, so the four waves of a workgroup write ONE dense, advancing window of 4 x 2 rows instead of
-// four separate runs a quarter of the tile apart.
+// Which ant of the workgroup's tile the j-th ant of wave `w` is: every wave takes one contiguous run.  (The waves taking
+// alternating 2-ant groups — one dense advancing window per workgroup — measured 2 % slower: profiles/r03/ilv_ab.txt.)
 __device__ __forceinline__ int prc_tile_ant(const int w, const int j, const int run, const int nwaves)
 {
-#ifdef PRC_INTERLEAVE_WAVES
-    return (j >> 1) * (2 * nwaves) + w * 2 + (j & 1);
-#else
     (void)nwaves;
     return w * run + j;
-#endif
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -460,24 +442,14 @@ k_perceive(const KP p, const float *__restrict__ cells, float *__restrict__ obs,
     // workgroup, not four times.  Same instructions on the same inputs: the frames are bit-identical.
     // Same-box A/B on k_perceive (profiles/r03/prologue_ab.txt): c3 -2.7 %, c4 -1.5 %, c5 -2.5 %, small batches with rocks
     // -3 ... -9 %, without rocks (nothing to overlap with) +-0.
-#ifndef PRC_NO_EPILOGUE_PREFETCH
     // The epilogue's inputs are fetched HERE, in front of the prologue's barrier (which waits for them: from there on the
     // compiler knows them complete).  Fetched at the wave's end they are one more memory round trip during which the wave
     // keeps its slot and its workgroup's LDS for nothing — and, vector-memory operations retiring in order, a wait for every
     // observation store of the run; fetched in front of the loop without a wait the compiler can see, the epilogue's first
     // use of them became `vmcnt(0)`, the same wait.  (Clamped lanes: every lane loads a valid ant.)
     const size_t a_pre = eN + (size_t)min(PRC_ANT(min(lane, max(n_run, 1) - 1)), N - 1);
-    const float pre_hold = STQ_LD(p.s.holding[a_pre]);
-    const float pre_seed = (agent_state || POLICY) ? STQ_LD(p.s.seed[a_pre]) : 0.0f;
-#endif
-#ifdef PRC_ABL_NO_PROLOGUE // ablation: no global load, no sincos, no barrier in front of the loop
-    if (lane < n_run) {
-        AntFrame fr;
-        fr.cx = 10.0 + lane; fr.cy = 20.0 + wave; fr.ct = 1.0; fr.st = 0.0;
-        frames[lane] = fr;
-        rmask[lane] = 0u;
-    }
-#else
+    const float pre_hold = p.s.holding[a_pre];
+    const float pre_seed = (agent_state || POLICY) ? p.s.seed[a_pre] : 0.0f;
     {
         // the two waves rotate with the workgroup index (wave 0 has the net at the end of a POLICY launch)
         const uint32_t wsel = (blockIdx.x >> 3) + (blockIdx.x >> 8);
@@ -503,19 +475,9 @@ k_perceive(const KP p, const float *__restrict__ cells, float *__restrict__ obs,
                     const size_t a = eN + (size_t)ant;
                     AntFrame *fr = reinterpret_cast<AntFrame *>(smem + lo.wave0 + (size_t)w2 * lo.per_wave + lo.frame) + j2;
                     // (all three loads in front of the sincos: one memory round trip, not two)
-#ifdef PRC_ABL_HASH_FRAMES // ablation: no load in the prologue — the ants stand at hashed places (same spread, no memory round trip)
-                    const uint32_t hsh = (uint32_t)a * 2654435761u;
-                    const double th = (double)(hsh >> 20) * (6.283185307179586 / 4096.0), x = (double)((hsh >> 4) % (uint32_t)W) + 0.25,
-                                 y = (double)((hsh >> 12) % (uint32_t)H) + 0.25;
-#else
-                    const double th = STQ_LD(p.s.theta[a]), x = STQ_LD(p.s.x[a]), y = STQ_LD(p.s.y[a]);
-#endif
+                    const double th = p.s.theta[a], x = p.s.x[a], y = p.s.y[a];
                     double sn, cs;
-#ifdef PRC_ABL_NO_SINCOS // ablation: no sincos (the patch is not rotated, the centre not shifted: same gather locality)
-                    sn = which ? 0.0 : 1.0; cs = (th > 100.0) ? 1.0 : 0.0;
-#else
                     sincos(which ? th : th + PI_D * 0.5, &sn, &cs);
-#endif
                     if (which) {
                         fr->cx = x + cs * p.fwd_delta;
                         fr->cy = y + sn * p.fwd_delta;
@@ -547,7 +509,6 @@ k_perceive(const KP p, const float *__restrict__ cells, float *__restrict__ obs,
             rmask[lane] = rm;
         }
     }
-#endif
     PRC_STAMP(1);
     wave_lds_sync();
     if (n_run <= 0) { // (no barrier below: waves run independently from here on — but for the policy's hand-over)
@@ -562,42 +523,6 @@ k_perceive(const KP p, const float *__restrict__ cells, float *__restrict__ obs,
     const bool explore = p.explore_on != 0;
     constexpr bool has_obs = HAS_OBS;
     constexpr bool has_rows = HAS_OBS || POLICY; // the perceived values are materialised (staging / tile image)
-    // ablations: compile-time only (variant builds for profiles/, results are wrong by design)
-#ifdef PRC_ABL_NO_GATHER
-    constexpr bool abl_gather = true;
-#else
-    constexpr bool abl_gather = false;
-#endif
-#ifdef PRC_ABL_NO_STORE
-    constexpr bool abl_store = true;
-#else
-    constexpr bool abl_store = false;
-#endif
-#ifdef PRC_ABL_NO_MARK
-    constexpr bool abl_mark = true;
-#else
-    constexpr bool abl_mark = false;
-#endif
-#ifdef PRC_ABL_STORE_REGS // the copy-out stores take register values: no LDS read in front of them
-    constexpr bool abl_regs = true;
-#else
-    constexpr bool abl_regs = false;
-#endif
-#ifdef PRC_ABL_NO_MATH // no float64 cell-index arithmetic (the lane number stands in for the cell)
-    constexpr bool abl_math = true;
-#else
-    constexpr bool abl_math = false;
-#endif
-#ifdef PRC_ABL_NO_LOAD // no gather instruction in the loop (no vmcnt coupling between loads and the stores in front of them)
-    constexpr bool abl_load = true;
-#else
-    constexpr bool abl_load = false;
-#endif
-#ifdef PRC_ABL_NO_STAGE // no LDS staging writes
-    constexpr bool abl_stage = true;
-#else
-    constexpr bool abl_stage = false;
-#endif
     const float inv_max = 1.0f / (float)p.max_val;
     const float g_now = (float)p.g_now;                       // scaled mode: v = u * f0^S ...
     const float cut = p.scaled ? (float)p.threshold : 0.0f;   // ... and 0 below the 0.01 cut
@@ -612,25 +537,7 @@ k_perceive(const KP p, const float *__restrict__ cells, float *__restrict__ obs,
     // is straight-line and unconditional (out-of-range ants / lanes are clamped onto valid ones and redo
     // identical work: stores of the same value to the same address), so the compiler can count outstanding
     // operations: the wait for group g's gathers leaves group g+1's gathers and group g-1's stores in flight.
-#ifdef PRC_LANE_2X2
-    // (variant build) lanes 4 b .. 4 b + 3 take a 2 x 2 sub-block of the patch instead of four cells of one patch row: the four
-    // lanes the address path handles together then fall into one or two record lines instead of one to three
-    const int q = [&]() {
-        const int l = lane < PP ? lane : PP - 1, hb = P >> 1, nb = hb * hb * 4;
-        int r, c;
-        if (l < nb) {
-            const int b = l >> 2, w = l & 3;
-            r = 2 * (b / hb) + (w >> 1);
-            c = 2 * (b % hb) + (w & 1);
-        } else {
-            const int m = l - nb; // (odd P: the last column top to bottom, then the rest of the last row)
-            if (m < P) { r = m; c = P - 1; } else { r = P - 1; c = m - P; }
-        }
-        return r * P + c;
-    }();
-#else
     const int q = lane < PP ? lane : PP - 1; // lanes beyond the perception clamp onto its last cell
-#endif
     const double of_px = (double)(q % P - p.r) * p.delta; // coords[a][b] = (arange[b], arange[a]) * DELTA, RL_api.py:92-93
     const double of_py = (double)(q / P - p.r) * p.delta;
     const bool mask_q = p.has_mask ? p.mask[q] != 0 : true;
@@ -638,22 +545,14 @@ k_perceive(const KP p, const float *__restrict__ cells, float *__restrict__ obs,
     // A lane whose gathered record is never used (a masked cell when no reward counts explored cells) takes
     // the address of the wave's first needed lane: the CU's address path works through a scattered gather at
     // about one distinct address per clock, and a lane on an address that is fetched anyway costs nothing.
-#ifdef PRC_ABL_MERGE_MASKED // ablation: masked lanes never gather their own cell (explored counts are then wrong)
-    const bool own = mask_q;
-#else
     const bool own = mask_q || explore;
-#endif
     const unsigned long long need_mask = __ballot(own);
     const int src_lane = own ? lane : (need_mask ? __builtin_ctzll(need_mask) : 0);
 
     // record index of cell (ix, iy): row-major, or blocks of 2 x 4 cells per 128-byte line (KP::tiled, rec_xy in antsrl_util.h)
     const bool tiled = p.tiled != 0;
 #define PRC_SLOT(ix, iy) (tiled ? tiled_slot((ix), (iy), H) : (uint32_t)((ix) * H + (iy)))
-#if defined(PRC_GATHER_NT)
-#define PRC_LOAD4(ptr) __builtin_nontemporal_load(reinterpret_cast<const stream_f4 *>(ptr))
-#else
-#define PRC_LOAD4(ptr) (*reinterpret_cast<const stream_f4 *>(ptr))
-#endif
+#define PRC_LOAD4(ptr) (*reinterpret_cast<const stream_f4 *>(ptr)) // (cached: as nt loads the gathers lose their L1 hits, +5 %)
 #define PRC_FETCH(G0, GRP)                                                                               \
     {                                                                                                    \
         _Pragma("unroll") for (int u = 0; u < PRC_UNROLL; ++u)                                           \
@@ -662,8 +561,8 @@ k_perceive(const KP p, const float *__restrict__ cells, float *__restrict__ obs,
             const AntFrame fr = frames[j_]; /* wave-uniform address: LDS broadcast */                    \
             const double rx = fr.ct * of_px - fr.st * of_py; /* RL_api.py:110-111 */                     \
             const double ry = fr.st * of_px + fr.ct * of_py;                                             \
-            int ix = abl_math ? lane + j_ : (int)rint(rx + fr.cx);       /* :114-117 half to even */     \
-            int iy = abl_math ? lane : (int)rint(ry + fr.cy);                                            \
+            int ix = (int)rint(rx + fr.cx);                              /* :114-117 half to even */     \
+            int iy = (int)rint(ry + fr.cy);                                                              \
             if (wrap_pow2) { /* :118-119; two's complement AND is the floor-mod for a power of two */    \
                 ix &= W - 1; iy &= H - 1;                                                                \
             } else if (wrap_fast) { /* |ix| < 2W: unsigned min picks the in-range candidate */           \
@@ -678,9 +577,7 @@ k_perceive(const KP p, const float *__restrict__ cells, float *__restrict__ obs,
         _Pragma("unroll") for (int u = 0; u < PRC_UNROLL; ++u)                                           \
         {                                                                                                \
             const uint32_t gc_ = abl_gather ? (uint32_t)lane : (uint32_t)__shfl((int)GRP.cell[u], src_lane); \
-            if (abl_load) { /* ablation: no memory operation at all in front of the stores */            \
-                GRP.pv[u][0] = (float)gc_; GRP.pv[u][1] = 1.0f; GRP.fd[u] = 2.0f; GRP.mt[u] = gc_;       \
-            } else if (ILV) { /* one {p0, p1, food, META} record per cell: a single 16-byte gather */     \
+            if (ILV) { /* one {p0, p1, food, META} record per cell: a single 16-byte gather */     \
                 const stream_f4 t = PRC_LOAD4(ph + (size_t)gc_ * 4);                                     \
                 GRP.pv[u][0] = t.x; GRP.pv[u][1] = t.y; GRP.fd[u] = t.z; GRP.mt[u] = __float_as_uint(t.w); \
             } else {                                                                                     \
@@ -696,25 +593,14 @@ k_perceive(const KP p, const float *__restrict__ cells, float *__restrict__ obs,
         int ix[PRC_UNROLL], iy[PRC_UNROLL];
         float pv[PRC_UNROLL][C], fd[PRC_UNROLL];
     };
-    PrcGrp gA, gB;
-#if PRC_DEPTH >= 2
-    PrcGrp gC;
-#endif
-#if PRC_DEPTH == 3
-    PrcGrp gD;
-#endif
+    PrcGrp gA, gB, gC;
     uint32_t cntv = 0u; // lane j: unexplored cells in the patch of the wave's j-th ant
     // copy-out state: elements per 128-byte line / per 16 bytes, the run's first row, the aligned line the LDS
     // image currently starts at, and how many image elements in front of the next row are already taken
     constexpr uint32_t LINE = OBS16 ? 64u : 32u, VEC = OBS16 ? 8u : 4u, ESZ = OBS16 ? 2u : 4u;
     unsigned char *run0 = reinterpret_cast<unsigned char *>(obs) + ((size_t)e * N + (size_t)PRC_ANT(0)) * row * ESZ;
-#ifndef PRC_FLUSH_LINES
     uint32_t carry = has_obs ? (uint32_t)(((uintptr_t)run0 & 15) / ESZ) : 0u;
-#else
-    uint32_t carry = has_obs ? (uint32_t)(((uintptr_t)run0 & 127) / ESZ) : 0u;
-#endif
-    unsigned char *line_base = run0 - (size_t)carry * ESZ;
-    (void)LINE; (void)VEC; (void)line_base; (void)abl_store; (void)abl_regs;
+    (void)LINE; (void)VEC;
     // ---- what happens to one group once its gathers are back: counts / marks, channel values, LDS staging, copy-out
     auto process = [&](const PrcGrp &g, const int j0) __attribute__((always_inline)) {
 #pragma unroll
@@ -759,9 +645,7 @@ k_perceive(const KP p, const float *__restrict__ cells, float *__restrict__ obs,
                     v_rock = any ? 1.0f : 0.0f;
                 }
                 const bool m = mask_q; // RL_api.py:147-148: mask*(p+1)-1 == -1 on masked cells
-                if (abl_stage) {
-                    asm volatile("" ::"v"(v_ants), "v"(pvs[0]), "v"(pvs[1]), "v"(v_area), "v"(v_wall), "v"(g.fd[u]), "v"(v_rock));
-                } else if (OBS16) {
+                if (OBS16) {
                     // bfloat16 observations: the same staging and copy-out on 2-byte elements (8 per 16 bytes)
                     // (POLICY: straight into the workgroup's tile image, row = the ant's index in the tile; a clamped
                     // duplicate of the run's last ant has no row of its own)
@@ -781,12 +665,12 @@ k_perceive(const KP p, const float *__restrict__ cells, float *__restrict__ obs,
                 }
             }
         }
-#ifndef PRC_FLUSH_LINES // the three-store copy-out (antsrl_flush.h: flush_plan_f32 / flush_plan_b16)
-        if (has_obs) {
+        if (has_obs) { // the three-store copy-out (antsrl_flush.h: flush_plan_f32 / flush_plan_b16)
             // The group's rows are contiguous in memory and leave as ONE run: 16-byte stores over the interior
             // pieces (the first 128 / 64 of them start on a 128-byte line), one element-wide store for the edge
-            // elements; lanes with nothing left repeat a valid store.  Measured against the whole-line copy-out
-            // with carry (-DPRC_FLUSH_LINES) on one box: 0.252 vs 0.267 ms.
+            // elements; lanes with nothing left repeat a valid store.  (The whole-line copy-out with a carry — every store
+            // instruction covering whole 128-byte lines — measured slower at every stage of the kernel, 0.2444 against
+            // 0.2212 ms last: DESIGN.md, profiles/r03/lines_ab.txt; the code is in profiles/r04/perceive_cleanup.patch.)
             wave_lds_sync();
             const uint32_t rowp = (j0 + 1 < n_run) ? 2u * row : row; // (odd tail of the run: one row)
             if (OBS16) {
@@ -811,138 +695,22 @@ k_perceive(const KP p, const float *__restrict__ cells, float *__restrict__ obs,
                 const uint32_t mis = (uint32_t)(((uintptr_t)dst >> 2) & 3);
                 float *dst_al = dst - mis;
                 const FlushPlanF32 f = flush_plan_f32((uint32_t)lane, mis, rowp, (uint32_t)((uintptr_t)dst_al >> 4) & 7u);
-                float4 v1, v2, v3;
-                float ve;
-                if (abl_regs) {
-                    v1 = make_float4(g.pv[0][0], g.pv[0][1], g.fd[0], 1.0f); v2 = make_float4(g.pv[1][0], g.pv[1][1], g.fd[1], 2.0f);
-                    v3 = v1; ve = g.fd[0];
-                } else {
-                    v1 = reinterpret_cast<const float4 *>(stage)[f.j1];
-                    v2 = reinterpret_cast<const float4 *>(stage)[f.j2];
-                    v3 = reinterpret_cast<const float4 *>(stage)[f.j3];
-                    ve = stage[f.fe];
-                }
-#ifdef PRC_STORE_AUX // (variant build) the 16-byte copy-out stores as raw buffer stores with the cache-policy bits PRC_STORE_AUX (1 sc0, 2 nt, 16 sc1)
-                const auto st_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)obs, (short)0, 0x7FFFFFFF, 0x00020000);
-#define PRC_ST16(PTR, V)                                                                                                      \
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(prc_u4, (V)), st_rsrc,                                          \
-                                           (int)((uintptr_t)(PTR) - (uintptr_t)obs), 0, PRC_STORE_AUX)
-#else
-#define PRC_ST16(PTR, V) store_stream((PTR), (V))
-#endif
-#ifdef PRC_ABL_LINE_STORES2 // ablation (wrong bytes): whole 128-byte lines, every line written ONCE — a line belongs to the group
-                            // its last byte falls into (what a copy-out from a run-sized LDS image would issue)
-                {
-                    const uintptr_t lo = ((uintptr_t)dst + 127) & ~(uintptr_t)127, hi = ((uintptr_t)dst + 4u * rowp + 127) & ~(uintptr_t)127;
-                    float4 *l0 = reinterpret_cast<float4 *>(lo);
-                    const uint32_t n4 = (uint32_t)((hi - lo) >> 4);
-                    PRC_ST16(l0 + min((uint32_t)lane, n4 - 1), v1);
-                    PRC_ST16(l0 + min((uint32_t)lane + 64u, n4 - 1), v2);
-                    PRC_ST16(l0 + min((uint32_t)lane + 128u, n4 - 1), v3);
-                    (void)ve;
-                }
-#elif defined(PRC_ABL_LINE_STORES) // ablation (wrong bytes): the probe's pattern — the group's bytes rounded OUT to whole 128-byte lines,
-                           // three 16-byte stores per lane, no element-wide edge store
-                {
-                    float4 *l0 = reinterpret_cast<float4 *>((uintptr_t)dst & ~(uintptr_t)127);
-                    const uint32_t n4 = (uint32_t)(((((uintptr_t)dst & 127) + 4u * rowp + 127u) & ~127u) >> 4);
-                    store_stream(l0 + min((uint32_t)lane, n4 - 1), v1);
-                    store_stream(l0 + min((uint32_t)lane + 64u, n4 - 1), v2);
-                    store_stream(l0 + min((uint32_t)lane + 128u, n4 - 1), v3);
-                    (void)ve;
-                }
-#else
+                const float4 v1 = reinterpret_cast<const float4 *>(stage)[f.j1];
+                const float4 v2 = reinterpret_cast<const float4 *>(stage)[f.j2];
+                const float4 v3 = reinterpret_cast<const float4 *>(stage)[f.j3];
+                const float ve = stage[f.fe];
                 if (!abl_store) {
-                    PRC_ST16(reinterpret_cast<float4 *>(dst_al) + f.j1, v1);
-                    PRC_ST16(reinterpret_cast<float4 *>(dst_al) + f.j2, v2);
-                    PRC_ST16(reinterpret_cast<float4 *>(dst_al) + f.j3, v3);
-#ifndef PRC_ABL_NO_EDGE // (ablation, variant build: the element-wide edge store dropped — wrong edge elements)
+                    store_stream(reinterpret_cast<float4 *>(dst_al) + f.j1, v1);
+                    store_stream(reinterpret_cast<float4 *>(dst_al) + f.j2, v2);
+                    store_stream(reinterpret_cast<float4 *>(dst_al) + f.j3, v3);
                     store_stream(dst_al + f.fe, ve);
-#else
-                    (void)ve;
-#endif
                 }
-#endif
                 // the next group's 16-byte misalignment
                 carry = (uint32_t)(((uintptr_t)(reinterpret_cast<float *>(obs) + ((size_t)e * N + (size_t)PRC_ANT(j0 + 2)) * row) >> 2) & 3);
             }
             wave_lds_sync();
         }
-#else
-        if (has_obs) {
-            // whole-line copy-out with carry (antsrl_flush.h): every store instruction covers whole aligned
-            // 128-byte lines of this wave's own rows
-            wave_lds_sync();
-            const uint32_t rowp = (j0 + 1 < n_run) ? 2u * row : row; // (odd tail of the run: one row)
-            const LineFlush f = line_flush(carry, rowp, j0 == 0, LINE, VEC);
-            if (OBS16) {
-                const uint16_t *st16 = reinterpret_cast<const uint16_t *>(stage);
-                uint16_t *lb = reinterpret_cast<uint16_t *>(line_base);
-                const uint32_t g1 = line_piece((uint32_t)lane, 0, f), g2 = line_piece((uint32_t)lane, 1, f);
-                const uint4 w1 = reinterpret_cast<const uint4 *>(st16)[g1];
-                const uint4 w2 = reinterpret_cast<const uint4 *>(st16)[g2];
-                const uint16_t wl = st16[f.nl * LINE + min((uint32_t)lane, max(f.left, 1u) - 1u)]; // the next carry
-                if (!abl_store) {
-                    store_stream(reinterpret_cast<uint4 *>(lb) + g1, w1);
-                    store_stream(reinterpret_cast<uint4 *>(lb) + g2, w2);
-                    if (f.head) { // first flush of the run only: the elements in front of the first whole piece
-                        const uint32_t h = carry + min((uint32_t)lane, f.head - 1u);
-                        store_stream(lb + h, st16[h]);
-                    }
-                }
-                wave_lds_sync();
-                if ((uint32_t)lane < f.left) reinterpret_cast<uint16_t *>(stage)[lane] = wl;
-            } else {
-                float *lb = reinterpret_cast<float *>(line_base);
-                const uint32_t j1 = line_piece((uint32_t)lane, 0, f), j2 = line_piece((uint32_t)lane, 1, f),
-                               j3 = line_piece((uint32_t)lane, 2, f);
-                float4 v1, v2, v3;
-                if (abl_regs) {
-                    v1 = make_float4(g.pv[0][0], g.pv[0][1], g.fd[0], 1.0f); v2 = make_float4(g.pv[1][0], g.pv[1][1], g.fd[1], 2.0f);
-                    v3 = v1;
-                } else {
-                    v1 = reinterpret_cast<const float4 *>(stage)[j1];
-                    v2 = reinterpret_cast<const float4 *>(stage)[j2];
-                    v3 = reinterpret_cast<const float4 *>(stage)[j3];
-                }
-                const float vl = stage[f.nl * LINE + min((uint32_t)lane, max(f.left, 1u) - 1u)]; // the next carry
-                if (!abl_store) {
-                    store_stream(reinterpret_cast<float4 *>(lb) + j1, v1);
-                    store_stream(reinterpret_cast<float4 *>(lb) + j2, v2);
-                    store_stream(reinterpret_cast<float4 *>(lb) + j3, v3);
-                    if (f.head) { // first flush of the run only: the <= 3 floats in front of the first whole piece
-                        const uint32_t h = carry + min((uint32_t)lane, f.head - 1u);
-                        store_stream(lb + h, stage[h]);
-                    }
-                }
-                wave_lds_sync();
-                if ((uint32_t)lane < f.left) stage[lane] = vl;
-            }
-            line_base += (size_t)f.nl * 128;
-            carry = f.left;
-            wave_lds_sync();
-        }
-#endif
     };
-#if PRC_DEPTH == 3
-    // All four groups of a chunk (8 ants: the shipped run length) are gathered up front, then consumed in order: no
-    // gather of the chunk is ever issued behind a store, so no wait on a gather is a wait on a store's acknowledgement,
-    // and the gather latency is paid once per chunk.  Four register sets (+32 VGPRs over PRC_DEPTH 1).
-    for (int c0 = 0; c0 < n_run; c0 += 4 * PRC_UNROLL) {
-        PRC_FETCH(min(c0, n_run - 1), gA)
-        PRC_FETCH(min(c0 + PRC_UNROLL, n_run - 1), gB)
-        PRC_FETCH(min(c0 + 2 * PRC_UNROLL, n_run - 1), gC)
-        PRC_FETCH(min(c0 + 3 * PRC_UNROLL, n_run - 1), gD)
-        process(gA, c0);
-        if (c0 + PRC_UNROLL < n_run) {
-            process(gB, c0 + PRC_UNROLL);
-            if (c0 + 2 * PRC_UNROLL < n_run) {
-                process(gC, c0 + 2 * PRC_UNROLL);
-                if (c0 + 3 * PRC_UNROLL < n_run) process(gD, c0 + 3 * PRC_UNROLL);
-            }
-        }
-    }
-#elif PRC_DEPTH == 2
     // Two groups ahead.  Straight-line code per chunk of four groups (8 ants: the shipped run length), three register
     // sets in rotation and no copy between them (a copy of a pending load's destination is a wait for it; a loop would
     // make the compiler merge the back edge's pending loads into the loop head and drain them there).  When group g is
@@ -972,44 +740,12 @@ k_perceive(const KP p, const float *__restrict__ cells, float *__restrict__ obs,
         }
     }
     PRC_STAMP(7);
-#else
-    PRC_FETCH(0, gA)
-    // The loop is entered with NO load pending: the compiler's wait-count analysis merges the loop-entry state
-    // with the back-edge state, and a prologue gather still in flight at the loop head turns into a
-    // `vmcnt(2)` in the steady state, i.e. a wait for the previous group's observation stores half an
-    // iteration after they were issued.  (vmcnt(0), expcnt / lgkmcnt untouched.)
-    __builtin_amdgcn_s_waitcnt(0x0F70);
-    for (int j0 = 0; j0 < n_run; j0 += PRC_UNROLL) {
-        PRC_FETCH(min(j0 + PRC_UNROLL, n_run - 1), gB) // (clamped: harmless re-read at the end)
-        process(gA, j0);
-        gA = gB;
-    }
-#endif
 #undef PRC_FETCH
-#ifdef PRC_FLUSH_LINES
-    if (has_obs && carry && !abl_store) { // the run's last, partial line: element-wide stores (the next run owns the rest)
-        if (OBS16) {
-            if ((uint32_t)lane < carry)
-                store_stream(reinterpret_cast<uint16_t *>(line_base) + lane, reinterpret_cast<const uint16_t *>(stage)[lane]);
-        } else {
-            if ((uint32_t)lane < carry) store_stream(reinterpret_cast<float *>(line_base) + lane, stage[lane]);
-        }
-    }
-#endif
 
     // ---- agent_state (RL_api.py:160-162), reward.observation hooks, give_reward: lane j <-> the wave's j-th ant
-#ifdef PRC_ABL_NO_EPILOGUE // ablation: no per-ant loads / small stores behind the loop
-    if (false)
-#else
-    if (lane < n_run)
-#endif
-    {
+    if (lane < n_run) {
         const size_t a = eN + (size_t)PRC_ANT(lane);
-#ifndef PRC_NO_EPILOGUE_PREFETCH
         const float hold = pre_hold, seed = pre_seed;
-#else
-        const float hold = STQ_LD(p.s.holding[a]), seed = (agent_state || POLICY) ? STQ_LD(p.s.seed[a]) : 0.0f;
-#endif
         if (agent_state) {
             store_stream(agent_state + a * 2 + 0, hold);
             store_stream(agent_state + a * 2 + 1, seed);
@@ -1060,11 +796,7 @@ k_perceive(const KP p, const float *__restrict__ cells, float *__restrict__ obs,
     if constexpr (POLICY) {
         __syncthreads(); // every wave's rows and agent_state inputs are in the image
         const int t0 = seg * nwaves * run; // first ant of this workgroup's tile
-#ifndef PRC_ABL_NO_POLICY // (ablation, variant build: no net — the actions are not written)
         if (wave == 0)
-#else
-        if (false)
-#endif
             policy_tile(pol, pol_img, (uint32_t)(tile0 - pol_img), pol_as, (int)row, min(nwaves * run, N - t0), eN + (size_t)t0, lane);
     }
 }

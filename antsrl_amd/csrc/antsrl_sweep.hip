@@ -603,29 +603,20 @@ k_sweep_sep2(const KP p, const float *__restrict__ in, float *__restrict__ out, 
             // this input row convolved across the columns with v: tap column b multiplies in[. - b + R]; summed
             // centre first, then outwards (the one-column march's order)
             v2f h0 = FMA2(vh[R], nb0[R], (v2f)(0.0f)), h1 = FMA2(vh[R], nb1[R], (v2f)(0.0f));
-#ifndef SWEEP_ABL_NO_LO
             h0 = FMA2(vl[R], nb0[R], h0); h1 = FMA2(vl[R], nb1[R], h1);
-#endif
 #pragma unroll
             for (int d = 1; d <= R; ++d) {
-#ifndef SWEEP_ABL_NO_LO
                 h0 = FMA2(vh[R + d], nb0[R - d], h0); h1 = FMA2(vh[R + d], nb1[R - d], h1);
                 h0 = FMA2(vl[R + d], nb0[R - d], h0); h1 = FMA2(vl[R + d], nb1[R - d], h1);
                 h0 = FMA2(vh[R - d], nb0[R + d], h0); h1 = FMA2(vh[R - d], nb1[R + d], h1);
                 h0 = FMA2(vl[R - d], nb0[R + d], h0); h1 = FMA2(vl[R - d], nb1[R + d], h1);
-#else // (ablation, variant build: the lo halves of the taps dropped — how much of the kernel is FMA issue?)
-                h0 = FMA2(vh[R + d], nb0[R - d], h0); h1 = FMA2(vh[R + d], nb1[R - d], h1);
-                h0 = FMA2(vh[R - d], nb0[R + d], h0); h1 = FMA2(vh[R - d], nb1[R + d], h1);
-#endif
             }
             // position i + a - R += u[a] h (u in march order): ring slot (s + a - R) mod S
 #pragma unroll
             for (int a = 0; a < S; ++a) {
                 const int slot = (s + a - R + 2 * S) % S;
                 acc[slot][0] = FMA2(uh[a], h0, acc[slot][0]); acc[slot][1] = FMA2(uh[a], h1, acc[slot][1]);
-#ifndef SWEEP_ABL_NO_LO
                 acc[slot][0] = FMA2(ul[a], h0, acc[slot][0]); acc[slot][1] = FMA2(ul[a], h1, acc[slot][1]);
-#endif
             }
             { // position i - R just received its last contribution: the segment's row number i - 2R in march order
                 const int slot = (s - R + 2 * S) % S;

@@ -44,10 +44,10 @@ __device__ __forceinline__ void update_one_body(const KP &p, const int e, const 
     const size_t a = eN + (on ? tid : 0);
 
     // ---- every independent load first
-    double x = ST_LD(p.s.x[a]), y = ST_LD(p.s.y[a]);
+    double x = p.s.x[a], y = p.s.y[a];
     const double px0 = STP_LD(p.s.prev_x[a]), py0 = STP_LD(p.s.prev_y[a]); // used on a wall hit only; prefetched all the same
     const uint8_t rstate = STP_LD(p.s.reward_state[a]);
-    const double theta0 = ST_LD(p.s.theta[a]); // used on a wall hit only
+    const double theta0 = p.s.theta[a]; // used on a wall hit only
     float act[C];
 #pragma unroll
     for (int c = 0; c < C; ++c) act[c] = STP_LD(p.s.activation[a * C + c]);
@@ -87,7 +87,7 @@ __device__ __forceinline__ void update_one_body(const KP &p, const int e, const 
     if (hit) {
         x = px0;
         y = py0;
-        ST_ST(p.s.theta[a], theta0 + (u - 0.5)); // theta is NOT re-wrapped here
+        p.s.theta[a] = theta0 + (u - 0.5); // theta is NOT re-wrapped here
     }
     if (fw) fw->th = hit ? theta0 + (u - 0.5) : theta0; // (k_update_move: exactly what the move would load back)
 
@@ -163,15 +163,11 @@ __device__ __forceinline__ void update_one_body(const KP &p, const int e, const 
     // wall cell ignores the old value)
     float pold[C];
 #pragma unroll
-#ifndef UM_ABL_NO_DEPOSIT // (ablation, variant build: the scattered read-modify-write of the deposit cell)
-    for (int c = 0; c < C; ++c) pold[c] = out[(size_t)cell * PS + c];
-#else
-    for (int c = 0; c < C; ++c) pold[c] = 0.0f;
-#endif
+    for (int c = 0; c < C; ++c) pold[c] = (UM_ABL & 4) ? 0.0f : out[(size_t)cell * PS + c]; // (UM_ABL 4: ablation, antsrl_device.h)
     if (on) {
         if (moved) {
-            ST_ST(p.s.x[a], x);
-            ST_ST(p.s.y[a], y);
+            p.s.x[a] = x;
+            p.s.y[a] = y;
         }
         STP_ST(p.s.prev_x[a], x);
         STP_ST(p.s.prev_y[a], y);
@@ -214,11 +210,7 @@ __device__ __forceinline__ void update_one_body(const KP &p, const int e, const 
                         if (v < p.threshold || on_wall) v = 0.0;
                         v += (double)act[c];
                         if (p.has_max_val) v = fmin(v, p.max_val);
-#ifndef UM_ABL_NO_DEPOSIT
-                        out[(size_t)cell * PS + c] = (float)(v * inv_g_dep);
-#else
-                        if (v == 12345.678) out[0] = (float)v;
-#endif
+                        if (!(UM_ABL & 4) || v == 12345.678) out[(size_t)cell * PS + c] = (float)(v * inv_g_dep);
                         wrote = true;
                     } else if (on_wall) {
                         out[(size_t)cell * PS + c] = 0.0f;

@@ -136,11 +136,7 @@ __device__ __forceinline__ void wave_lds_sync()
 #define ANTSRL_MAX_DEVICES 64 // per-device launch bookkeeping (dynamic-LDS opt-in)
 typedef float stream_f4 __attribute__((ext_vector_type(4)));
 typedef uint32_t stream_u4 __attribute__((ext_vector_type(4)));
-#ifdef ANTSRL_STORE_PLAIN // A/B (variant builds): default cache policy for the step outputs
-#define ANTSRL_NT_STORE(v, p) (*(p) = (v))
-#else
-#define ANTSRL_NT_STORE(v, p) __builtin_nontemporal_store(v, p)
-#endif
+#define ANTSRL_NT_STORE(v, p) __builtin_nontemporal_store(v, p) // (plain stores: k_perceive 0.278 against 0.233 ms)
 __device__ __forceinline__ void store_stream(float *dst, float v) { ANTSRL_NT_STORE(v, dst); }
 __device__ __forceinline__ void store_stream(uint16_t *dst, uint16_t v) { ANTSRL_NT_STORE(v, dst); }
 __device__ __forceinline__ void store_stream(uint4 *dst, const uint4 &v)
@@ -153,33 +149,14 @@ __device__ __forceinline__ void store_stream(float4 *dst, const float4 &v)
     ANTSRL_NT_STORE((stream_f4{v.x, v.y, v.z, v.w}), reinterpret_cast<stream_f4 *>(dst));
 }
 
-// Per-ant struct-of-arrays state (read and written once per step by the per-environment kernels): ANTSRL_STATE_NT (variant
-// build, A/B) moves it with nt loads / stores so that it does not take Infinity Cache space from the cell records.
-#ifdef ANTSRL_STATE_NT
-#define ST_LD(lv) __builtin_nontemporal_load(&(lv))
-#define ST_ST(lv, v) __builtin_nontemporal_store((v), &(lv))
-#else
-#define ST_LD(lv) (lv)
-#define ST_ST(lv, v) ((lv) = (v))
-#endif
-// ... and the arrays ONLY the per-environment kernels touch (previous position, mandibles, tint, activation, the sparse-update
-// lists, the actions) are streamed: they are read and written once per step by k_update_move and by nobody else, and as `nt`
-// accesses they take no Infinity Cache space from the ~205 MB of cell-record lines the perception gathers re-use step after
-// step (c3, same box: 0.2536 -> 0.2500 ms/step, k_perceive 0.2092 -> 0.2066, k_update_move 0.0472 -> 0.0466; c2 / c5
-// unchanged — profiles/r03/state_nt2_ab.txt; ANTSRL_STATE_PLAIN: the A/B).  k_perceive's inputs (x, y, theta, holding, seed)
-// stay cached: streamed, too, they cost k_perceive more than the cache space is worth (ANTSRL_STATE_NT above, STQ_LD below).
-#ifdef ANTSRL_STATE_NT3 // (variant) k_perceive's own reads of the per-ant state as nt loads: measured +2 % on k_perceive
-#define STQ_LD(lv) __builtin_nontemporal_load(&(lv))
-#else
-#define STQ_LD(lv) ST_LD(lv)
-#endif
-#ifndef ANTSRL_STATE_PLAIN
+// Per-ant struct-of-arrays state.  The arrays ONLY the per-environment kernels touch (previous position, mandibles, tint,
+// activation, the sparse-update lists, the actions) are streamed (STP_LD / STP_ST): they are read and written once per step
+// by k_update_move and by nobody else, and as `nt` accesses they take no Infinity Cache space from the ~205 MB of
+// cell-record lines the perception gathers re-use step after step (c3, same box: 0.2536 -> 0.2500 ms/step;
+// profiles/r03/state_nt2_ab.txt).  k_perceive's inputs (x, y, theta, holding, seed) stay cached: streamed, too, they cost
+// k_perceive more than the cache space is worth (state_nt_ab.txt: +2 %).
 #define STP_LD(lv) __builtin_nontemporal_load(&(lv))
 #define STP_ST(lv, v) __builtin_nontemporal_store((v), &(lv))
-#else
-#define STP_LD(lv) (lv)
-#define STP_ST(lv, v) ((lv) = (v))
-#endif
 
 // The smallest double T with sqrt(T) >= r, so that  sqrt(d2) < r  <=>  d2 < T  exactly (sqrt is correctly
 // rounded and monotone): the per-cell rock test (circle_obstacles.py via RL_api.py:132-135,
@@ -217,10 +194,5 @@ static inline unsigned grid_for(size_t n)
 // profiles/r02/altorder_ab.txt).  Speed only: any order gives the same results.
 __device__ __forceinline__ int env_of_block(const int i, const int E, const uint32_t seq)
 {
-#ifdef ANTSRL_ENV_ORDER_FORWARD // (variant build for the A/B)
-    (void)E; (void)seq;
-    return i;
-#else
     return (seq & 1u) ? E - 1 - i : i;
-#endif
 }

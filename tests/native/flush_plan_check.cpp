@@ -59,56 +59,3 @@ extern "C" long flush_plan_violations(int verbose)
                 }
     return bad;
 }
-
-// Whole-line copy-out with carry (line_flush / line_piece): simulate complete runs — every first-row
-// misalignment against a 128-byte line, every row length the cell-meta path accepts, run lengths 1..9 (odd and
-// even: one-row tails) — exactly as k_perceive drives it, and check that every element of the run is stored
-// with its own value, that nothing outside the run is touched, and that every 16-byte store instruction
-// covers whole lines except at the head of the run.
-static long line_case(uint32_t LINE, uint32_t VEC, uint32_t nk, uint32_t c0, uint32_t row, uint32_t n_run, int verbose)
-{
-    long bad = 0;
-    static int img[2 * 368 + 192], mem[10 * 368 + 512];
-    const uint32_t mem_n = c0 + n_run * row + LINE; // element c0 = first element of the run
-    for (uint32_t i = 0; i < mem_n; ++i) mem[i] = -1;
-    uint32_t carry = c0, line_base = 0; // element index of the image's start in `mem`
-    for (uint32_t j0 = 0; j0 < n_run; j0 += 2) {
-        const uint32_t rowp = (j0 + 1 < n_run) ? 2 * row : row;
-        for (uint32_t t = 0; t < rowp; ++t) img[carry + t] = (int)(j0 * row + t); // value = index within the run
-        const LineFlush f = line_flush(carry, rowp, j0 == 0, LINE, VEC);
-        if (f.n16 <= f.jstart) { ++bad; if (verbose) printf("empty flush\n"); continue; }
-        for (uint32_t k = 0; k < nk; ++k)
-            for (uint32_t lane = 0; lane < 64; ++lane) {
-                const uint32_t j = line_piece(lane, k, f);
-                if (j < f.jstart || j >= f.n16) { ++bad; continue; }
-                for (uint32_t t = 0; t < VEC; ++t) mem[line_base + j * VEC + t] = img[j * VEC + t];
-            }
-        for (uint32_t lane = 0; lane < 64 && f.head; ++lane) {
-            const uint32_t h = carry + (lane < f.head - 1 ? lane : f.head - 1);
-            mem[line_base + h] = img[h];
-        }
-        // every piece [jstart, n16) must have been covered by the nk instructions
-        for (uint32_t j = f.jstart; j < f.n16; ++j)
-            if (mem[line_base + j * VEC] != img[j * VEC]) { ++bad; if (verbose && bad < 5) printf("piece %u not stored (LINE=%u row=%u c0=%u)\n", j, LINE, row, c0); }
-        for (uint32_t t = 0; t < f.left; ++t) img[t] = img[f.nl * LINE + t];
-        line_base += f.nl * LINE;
-        carry = f.left;
-    }
-    for (uint32_t t = 0; t < carry; ++t) mem[line_base + t] = img[t];
-    for (uint32_t i = 0; i < mem_n; ++i) {
-        const int want = (i >= c0 && i < c0 + n_run * row) ? (int)(i - c0) : -1;
-        if (mem[i] != want) { ++bad; if (verbose && bad < 5) printf("LINE=%u row=%u c0=%u n_run=%u: element %u holds %d, want %d\n", LINE, row, c0, n_run, i, mem[i], want); }
-    }
-    return bad;
-}
-
-extern "C" long line_flush_violations(int verbose)
-{
-    long bad = 0;
-    for (uint32_t row = 128; row <= 368; ++row)
-        for (uint32_t n_run = 1; n_run <= 9; ++n_run) {
-            for (uint32_t c0 = 0; c0 < 32; ++c0) bad += line_case(32, 4, 3, c0, row, n_run, verbose);
-            for (uint32_t c0 = 0; c0 < 64; ++c0) bad += line_case(64, 8, 2, c0, row, n_run, verbose);
-        }
-    return bad;
-}

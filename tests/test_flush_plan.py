@@ -17,6 +17,3 @@ def test_flush_plan_stays_inside_its_rows_and_covers_them(tmp_path):
     lib = C.CDLL(so)
     lib.flush_plan_violations.restype = C.c_long
     assert lib.flush_plan_violations(1) == 0
-    # k_perceive's whole-line copy-out with carry: complete runs simulated for every alignment / row length
-    lib.line_flush_violations.restype = C.c_long
-    assert lib.line_flush_violations(1) == 0
