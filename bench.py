@@ -228,6 +228,11 @@ def main():
     if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # The per-step all-gather is a small latency-bound collective: on RCCL's default-priority stream it shares a hardware
+        # queue with the step's kernels and every step pays two cross-stream hand-overs in series (k_perceive -> gather ->
+        # next k_update_move: +41 us per 0.24 ms step, measured with one rank); on a high-priority stream it gets a queue of
+        # its own and runs beside the next step (+4 us): profiles/r04/dist_overhead_ab.txt
+        os.environ.setdefault("TORCH_NCCL_HIGH_PRIORITY", "1")
         if force_dist:
             os.environ.setdefault("MASTER_PORT", "29533")
             os.environ.setdefault("RANK", "0")
@@ -323,12 +328,19 @@ def main():
     ev_slot = {rt: i for i, rt in enumerate(timed_steps)}
 
     def barrier():
-        gathered = stepper.drain()  # the last steps' gathers belong to the timed region
+        """-> (the last step's gathered batch, this rank's clock when ITS work was done).  The last steps' gathers belong to
+        the timed region: a rank's clock stops once its kernels AND the collectives it takes part in have completed
+        (drain + synchronize).  The closing dist.barrier() then lines the ranks up for the next region; its own latency
+        (a 1-element all-reduce plus two host synchronisations, ~0.5 ms = 10 % of a 20-step region) is not part of the K
+        steps, and the job's time is the MAX over the ranks of their completion times, all measured from the common start
+        behind the opening barrier."""
+        gathered = stepper.drain()
         torch.cuda.synchronize(dev)
+        t_done = time.perf_counter()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize(dev)
-        return gathered
+        return gathered, t_done
 
     gather_checks = 0
 
@@ -359,8 +371,8 @@ def main():
                 env.set_timing_events([evs.ev[NEV * ev_slot[(rep, t)] + i].value for i in range(NEV)])
             one_step(step_no)
             step_no += 1
-        gathered = barrier()
-        el = time.perf_counter() - t0
+        gathered, t_done = barrier()
+        el = t_done - t0
         if dist is not None:
             tmax = torch.tensor([el], dtype=torch.float64, device=dev)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
