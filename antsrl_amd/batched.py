@@ -43,10 +43,14 @@ def _ptr(t: Optional[torch.Tensor]):
 
 
 class BatchedAntsEnv:
-    def __init__(self, cfg: AntsCfg, device: Optional[torch.device] = None, obs_dtype: torch.dtype = torch.float32):
+    def __init__(self, cfg: AntsCfg, device: Optional[torch.device] = None, obs_dtype: torch.dtype = torch.float32,
+                 obs_row_stride=None):
         """obs_dtype: torch.float32 (the reference's values) or torch.bfloat16 (the same values rounded
         to nearest even: half the bytes per step; what the bf16 policy rounds its input to anyway —
-        antsrl_set_obs_format)."""
+        antsrl_set_obs_format).
+        obs_row_stride: None (dense, the default) or "line": every ant's row of P*P*K values starts on a 128-byte line
+        (antsrl_set_obs_row_stride; float32 7x7x7: 352 elements per row instead of 343).  `self.obs` keeps the reference's
+        shape [E, N, P, P, K] — then as a strided VIEW of `self.obs_padded` [E, N, stride], whose padding is zeros."""
         if obs_dtype not in (torch.float32, torch.bfloat16):
             raise ValueError("obs_dtype must be torch.float32 or torch.bfloat16")
         if not torch.cuda.is_available():
@@ -70,7 +74,11 @@ class BatchedAntsEnv:
             # The four step outputs are views of ONE device buffer (256-byte aligned pieces, the small ones
             # first): outputs_to_host() brings them over in a single copy.
             esz = 4 if obs_dtype == torch.float32 else 2
-            sizes = [("agent_state", E * N * 2 * 4), ("reward", E * N * 4), ("done", E), ("obs", E * N * P * P * K * esz)]
+            row = P * P * K
+            if obs_row_stride not in (None, "line"):
+                raise ValueError("obs_row_stride must be None or 'line'")
+            pitch = row if obs_row_stride is None else (row * esz + 127) // 128 * 128 // esz
+            sizes = [("agent_state", E * N * 2 * 4), ("reward", E * N * 4), ("done", E), ("obs", E * N * pitch * esz)]
             offs, total = {}, 0
             for name, nbytes in sizes:
                 offs[name] = total
@@ -82,9 +90,16 @@ class BatchedAntsEnv:
 
             def piece(name, nbytes, dtype, shape):
                 return self._out_flat[offs[name]:offs[name] + nbytes].view(dtype).view(shape)
-            self.obs = piece("obs", sizes[3][1], obs_dtype, (E, N, P, P, K))
             if obs_dtype == torch.bfloat16:
                 _lib.check(self.lib.antsrl_set_obs_format(self._h, 1), "set_obs_format")
+            if pitch == row:
+                self.obs = piece("obs", sizes[3][1], obs_dtype, (E, N, P, P, K))
+                self.obs_padded = None
+            else:  # rows a whole number of 128-byte lines apart; the reference's shape is a view of the padded buffer
+                self.obs_padded = piece("obs", sizes[3][1], obs_dtype, (E, N, pitch))
+                self.obs = self.obs_padded[..., :row].unflatten(-1, (P, P, K))
+                _lib.check(self.lib.antsrl_set_obs_row_stride(self._h, pitch), "set_obs_row_stride")
+            self.obs_row_pitch = pitch
             self.agent_state = piece("agent_state", sizes[0][1], torch.float32, (E, N, 2))
             self.reward = piece("reward", sizes[1][1], torch.float32, (E, N))
             self.done = piece("done", sizes[2][1], torch.uint8, (E,))
@@ -100,6 +115,12 @@ class BatchedAntsEnv:
             self._h = None
 
     # ------------------------------------------------------------------ helpers
+    @property
+    def _obs_buf(self):
+        """The tensor whose address the kernels get: `obs` itself (a caller may re-point it, like reward / done), or the
+        padded buffer `obs` is a view of (obs_row_stride="line")."""
+        return self.obs if self.obs_padded is None else self.obs_padded
+
     def _stream(self):
         if _RAW_STREAM is not None:  # same value as current_stream(device).cuda_stream, without the Stream object
             return C.c_void_p(_RAW_STREAM(self._dev_index))
@@ -210,7 +231,7 @@ class BatchedAntsEnv:
         if self.obs.dtype != torch.float32 and want_obs:
             raise _lib.AntsrlError("outputs_to_host: bfloat16 observations have no numpy dtype; use the device tensors")
         base, o = self._out_flat.data_ptr(), self._out_offs
-        if any(t.data_ptr() != base + o[k] for k, t in (("obs", self.obs), ("agent_state", self.agent_state),
+        if any(t.data_ptr() != base + o[k] for k, t in (("obs", self._obs_buf), ("agent_state", self.agent_state),
                                                          ("reward", self.reward), ("done", self.done))):
             # an output was re-pointed (e.g. at a RewardGather slot): plain per-tensor copies
             return (self.obs.cpu().numpy() if want_obs else None, self.agent_state.cpu().numpy(),
@@ -226,14 +247,20 @@ class BatchedAntsEnv:
         def piece(name, t):
             nb = t.numel() * t.element_size()
             return hb[o[name]:o[name] + nb].view(np.float32 if t.dtype == torch.float32 else np.uint8).reshape(tuple(t.shape)).copy()
-        return (piece("obs", self.obs) if want_obs else None, piece("agent_state", self.agent_state),
+        obs_h = None
+        if want_obs:
+            obs_h = piece("obs", self._obs_buf)
+            if self.obs_padded is not None:  # drop the padding on the host
+                c = self.cfg
+                obs_h = np.ascontiguousarray(obs_h[..., :c.pside * c.pside * c.n_channels]).reshape(tuple(self.obs.shape))
+        return (obs_h, piece("agent_state", self.agent_state),
                 piece("reward", self.reward), piece("done", self.done))
 
     def step(self, rotation, phero, want_obs: bool = True):
         """RLApi.step (RL_api.py:168-204) for all envs -> (obs, agent_state, reward, done)."""
         rot, ph = self._actions(rotation, phero)
         with self._on_device():
-            _lib.check(self.lib.antsrl_step(self._h, _ptr(rot), _ptr(ph), _ptr(self.obs if want_obs else None),
+            _lib.check(self.lib.antsrl_step(self._h, _ptr(rot), _ptr(ph), _ptr(self._obs_buf if want_obs else None),
                                             _ptr(self.agent_state), _ptr(self.reward), _ptr(self.done),
                                             self._stream()), "step")
         return self.obs, self.agent_state, self.reward, self.done
@@ -241,7 +268,7 @@ class BatchedAntsEnv:
     def observe(self, want_obs: bool = True):
         """RLApi.observation (RL_api.py:96-165) -> (obs, agent_state, reward)."""
         with self._on_device():
-            _lib.check(self.lib.antsrl_observe(self._h, _ptr(self.obs if want_obs else None),
+            _lib.check(self.lib.antsrl_observe(self._h, _ptr(self._obs_buf if want_obs else None),
                                                _ptr(self.agent_state), _ptr(self.reward), self._stream()),
                        "observe")
         return self.obs, self.agent_state, self.reward
@@ -267,7 +294,7 @@ class BatchedAntsEnv:
         j = self._dev(wall_jitter, torch.float64, (c.n_envs, c.n_ants))
         with self._on_device():
             _lib.check(self.lib.antsrl_step_update(self._h, _ptr(rot), _ptr(ph), _ptr(j),
-                                                   _ptr(self.obs if want_obs else None), _ptr(self.agent_state),
+                                                   _ptr(self._obs_buf if want_obs else None), _ptr(self.agent_state),
                                                    _ptr(self.reward), _ptr(self.done), self._stream()),
                        "step_update")
         return self.obs, self.agent_state, self.reward, self.done

@@ -33,7 +33,7 @@ bool antsrl_meta_supported(const KP &p);
 hipError_t antsrl_launch_move(const KP &p, const int8_t *rot, const int8_t *ph, uint8_t *done, int do_step, uint32_t seq,
                               hipStream_t st);
 hipError_t antsrl_launch_perceive(const KP &p, int cur, float *obs, float *agent_state, float *reward, int flags,
-                                  uint32_t seq, hipStream_t st, const PolArgs *pol);
+                                  uint32_t seq, hipStream_t st, const PolArgs *pol, uint32_t obs_pitch);
 bool antsrl_inloop_policy_supported(const KP &p);
 hipError_t antsrl_launch_policy_pack(unsigned char *pack, const float *w1, const float *b1, const float *w2, const float *b2,
                                      const float *w3, const float *b3, int F, hipStream_t st);
@@ -59,6 +59,7 @@ struct AntsHandle {
     int host_timestep;     // mirrors Environment.timestep (all envs step in lockstep)
     long long sweeps;      // scaled mode: updates since the units were last re-based
     bool obs_bf16;         // observation buffers are bfloat16 (antsrl_set_obs_format)
+    uint32_t obs_pitch;    // elements between two ants' observation rows (antsrl_set_obs_row_stride), 0 = dense
     bool need_wall_clear;  // scaled mode: initial grid may hold pheromone on wall cells
     hipEvent_t ev[ANTSRL_TIMING_EVENTS]; // measurement hook (antsrl_set_timing_events)
     bool ev_armed;
@@ -333,7 +334,7 @@ extern "C" int antsrl_create(const AntsCfg *cfg, void *workspace, size_t workspa
     h->cur = 0; h->steps_since_update = 0; h->need_full_collect = true; h->is_reset = false; h->episode_over = false; h->pend_update = false;
     h->pol = PolArgs{};
     h->sweeps = 0; h->need_wall_clear = false;
-    h->has_gen = false; h->episode_seed = 0; h->host_timestep = 1; h->obs_bf16 = false;
+    h->has_gen = false; h->episode_seed = 0; h->host_timestep = 1; h->obs_bf16 = false; h->obs_pitch = 0;
     h->ws_bytes = need;
     h->ev_armed = false;
     h->obs_seq = 0;
@@ -439,8 +440,25 @@ extern "C" int antsrl_set_obs_format(AntsHandle *h, int format)
 {
     if (!h) return fail(ANTSRL_E_INVALID, "NULL handle");
     if (format != ANTSRL_OBS_F32 && format != ANTSRL_OBS_BF16) return fail(ANTSRL_E_INVALID, "bad observation format %d", format);
+    if ((format == ANTSRL_OBS_BF16) != h->obs_bf16) h->obs_pitch = 0; // (a row stride is a whole number of lines of ONE element size)
     h->obs_bf16 = format == ANTSRL_OBS_BF16;
     if (!h->obs_bf16) h->pol = PolArgs{}; // (the in-loop policy reads bfloat16 rows)
+    return ANTSRL_OK;
+}
+
+extern "C" int antsrl_set_obs_row_stride(AntsHandle *h, int32_t stride_elems)
+{
+    if (!h) return fail(ANTSRL_E_INVALID, "NULL handle");
+    const int32_t row = h->p.PP * h->p.K, esz = h->obs_bf16 ? 2 : 4;
+    if (stride_elems == 0 || stride_elems == row) {
+        h->obs_pitch = 0;
+        return ANTSRL_OK;
+    }
+    if (stride_elems < row || ((long long)stride_elems * esz) % 128 != 0 || stride_elems > row + 128 / esz)
+        return fail(ANTSRL_E_INVALID, "obs row stride %d: 0 (dense) or the row's %d elements rounded up to whole 128-byte lines (%d)",
+                    stride_elems, row, (row * esz + 127) / 128 * 128 / esz);
+    if (!h->p.meta) return fail(ANTSRL_E_UNSUPPORTED, "antsrl_set_obs_row_stride needs the cell-meta path (ANTSRL_Q_CELL_META)");
+    h->obs_pitch = (uint32_t)stride_elems;
     return ANTSRL_OK;
 }
 
@@ -488,7 +506,9 @@ static int meta_observe(AntsHandle *h, const int8_t *rot, const int8_t *ph, floa
     e = antsrl_launch_perceive(h->p, h->cur, obs, agent_state, reward,
                                (stepping ? ACT_STEP : 0) | (obs ? ACT_HAS_OBS : 0) |
                                    ((obs || h->pol.pack) && h->obs_bf16 ? ACT_OBS_BF16 : 0), // (act-only: rows in LDS, bf16)
-                               h->obs_seq, st, &h->pol);
+                               h->obs_seq, st, &h->pol, h->obs_pitch);
+    if (e == hipErrorNotSupported)
+        return fail(ANTSRL_E_UNSUPPORTED, "a padded observation row stride and the in-loop policy exclude each other (the net reads a dense tile image)");
     if (e != hipSuccess) return hip_fail(e, "perceive");
     return ANTSRL_OK;
 }
@@ -506,6 +526,7 @@ static int do_step(AntsHandle *h, const int8_t *rot, const int8_t *ph, float *ob
         h->steps_since_update++;
         return ANTSRL_OK;
     }
+    if (obs && h->obs_pitch) return fail(ANTSRL_E_UNSUPPORTED, "antsrl_set_obs_row_stride needs the cell-meta path (ANTSRL_Q_CELL_META)");
     if (timed) (void)hipEventRecord(h->ev[2], st);
     static const int ablate = PROF_ENV("ANTSRL_ABLATE") ? atoi(PROF_ENV("ANTSRL_ABLATE")) & ~15 : 0; // profiling build only
     hipError_t e = antsrl_launch_act(h->p, rot, ph, h->cur, obs, agent_state, reward, done,
@@ -583,6 +604,7 @@ extern "C" int antsrl_observe(AntsHandle *h, float *obs, float *agent_state, flo
     if (!h->is_reset) return not_reset(h);
     if (h->p.meta)
         return meta_observe(h, nullptr, nullptr, obs, agent_state, reward, nullptr, false, (hipStream_t)stream, false);
+    if (obs && h->obs_pitch) return fail(ANTSRL_E_UNSUPPORTED, "antsrl_set_obs_row_stride needs the cell-meta path (ANTSRL_Q_CELL_META)");
     hipError_t e = antsrl_launch_act(h->p, nullptr, nullptr, h->cur, obs, agent_state, reward, nullptr,
                                      obs ? ACT_HAS_OBS | (h->obs_bf16 ? ACT_OBS_BF16 : 0) : 0, nullptr, 0,
                                      (hipStream_t)stream);

@@ -227,7 +227,7 @@ struct PrcOff {
     size_t total;
 };
 
-__host__ __device__ __forceinline__ PrcOff prc_offsets(int run, int PP, int K, int R, int nwaves, bool no_stage = false)
+__host__ __device__ __forceinline__ PrcOff prc_offsets(int run, int PP, int K, int R, int nwaves, bool no_stage = false, uint32_t pitch = 0)
 {
     PrcOff o;
     o.rock = 0;
@@ -237,6 +237,7 @@ __host__ __device__ __forceinline__ PrcOff prc_offsets(int run, int PP, int K, i
     o.stage = (uint32_t)align_up(o.rm + 4 * (size_t)run, 16);
     const size_t rowf = (size_t)PP * K;
     o.stride = (uint32_t)((2 * rowf + 32 + 3) / 4 * 4); // floats: misalignment / carry (< one 128-byte line) + two rows
+    if (2 * pitch > o.stride) o.stride = 2 * pitch;     // padded rows (PAD): two rows at the observation's row pitch
     o.per_wave = (uint32_t)align_up(o.stage + (no_stage ? 0 : 4 * (size_t)o.stride), 16); // (POLICY: the tile image is the staging)
     o.total = o.wave0 + (size_t)nwaves * o.per_wave;
     return o;
@@ -365,12 +366,18 @@ extern "C" int antsrl_debug_read_prc_trace(uint32_t *dst, int n_waves)
 // wave evaluates the in-loop policy on them at the end (policy_tile).  POLICY without HAS_OBS is the act-only rollout
 // (collect_agent_memory.py:189-199 with training=False needs the actions, nothing else): the rows exist in LDS only —
 // same image, same MFMAs, so the actions are bit-identical to the launch that also writes the tensor.
-template <int LAYOUT, bool OBS16, bool ILV, bool HAS_OBS, bool POLICY = false>
+// PAD (antsrl_set_obs_row_stride): the observation rows lie `pitch` elements apart, a whole number of 128-byte lines
+// (float32 7x7x7: 343 -> 352 elements = 11 lines): every 2-row group is then whole lines of this wave's own, copied out
+// with aligned 16-byte stores only — no misalignment, no edge store, no line shared with another wave.  The padding
+// elements are written as zeros.  Same values in the same [E][N][P][P][K] positions; the dense layout is the default.
+template <int LAYOUT, bool OBS16, bool ILV, bool HAS_OBS, bool POLICY = false, bool PAD = false>
 __global__ void __launch_bounds__(PRC_TPB, 4)
 k_perceive(const KP p, const float *__restrict__ cells, float *__restrict__ obs, float *__restrict__ agent_state,
-           float *__restrict__ reward, const int flags, const uint32_t seq, const int run, const int nseg, const PolArgs pol)
+           float *__restrict__ reward, const int flags, const uint32_t seq, const int run, const int nseg, const PolArgs pol,
+           const uint32_t pitch_arg)
 {
     static_assert(!POLICY || OBS16, "the in-loop policy reads bfloat16 rows");
+    static_assert(!PAD || (HAS_OBS && !POLICY), "padded rows: an observation tensor, no in-loop policy image");
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr int C = 2;
     const int tid = threadIdx.x;
@@ -379,7 +386,7 @@ k_perceive(const KP p, const float *__restrict__ cells, float *__restrict__ obs,
     const int N = p.N, W = p.W, H = p.H, K = p.K, P = p.P, PP = p.PP, R = p.R;
     const size_t G = (size_t)W * H;
 #ifdef PRC_TRACE
-    uint32_t *prc_tr = reinterpret_cast<uint32_t *>(smem + align_up(prc_offsets(run, PP, K, R, nwaves, POLICY).total, 16) +
+    uint32_t *prc_tr = reinterpret_cast<uint32_t *>(smem + align_up(prc_offsets(run, PP, K, R, nwaves, POLICY, PAD ? pitch_arg : 0u).total, 16) +
                                                     (POLICY ? 2 * (size_t)prc_policy_img_elems(PP * K) + 4 * 64 : 0)) + wave * PRC_TRACE_SLOTS;
     if (lane < PRC_TRACE_SLOTS) prc_tr[lane] = 0u;
     PRC_STAMP(0);
@@ -404,7 +411,7 @@ k_perceive(const KP p, const float *__restrict__ cells, float *__restrict__ obs,
         }
         e = env_of_block(e, p.E, seq); // (odd observations from the other end: antsrl_util.h)
     }
-    const PrcOff lo = prc_offsets(run, PP, K, R, nwaves, POLICY);
+    const PrcOff lo = prc_offsets(run, PP, K, R, nwaves, POLICY, PAD ? pitch_arg : 0u);
     double *rock = (double *)(smem + lo.rock);
     unsigned char *wbase = smem + lo.wave0 + (size_t)wave * lo.per_wave;
     AntFrame *frames = (AntFrame *)(wbase + lo.frame);
@@ -598,9 +605,22 @@ k_perceive(const KP p, const float *__restrict__ cells, float *__restrict__ obs,
     // copy-out state: elements per 128-byte line / per 16 bytes, the run's first row, the aligned line the LDS
     // image currently starts at, and how many image elements in front of the next row are already taken
     constexpr uint32_t LINE = OBS16 ? 64u : 32u, VEC = OBS16 ? 8u : 4u, ESZ = OBS16 ? 2u : 4u;
-    unsigned char *run0 = reinterpret_cast<unsigned char *>(obs) + ((size_t)e * N + (size_t)PRC_ANT(0)) * row * ESZ;
-    uint32_t carry = has_obs ? (uint32_t)(((uintptr_t)run0 & 15) / ESZ) : 0u;
+    const uint32_t pitch = PAD ? pitch_arg : row; // elements from one ant's row to the next
+    unsigned char *run0 = reinterpret_cast<unsigned char *>(obs) + ((size_t)e * N + (size_t)PRC_ANT(0)) * pitch * ESZ;
+    uint32_t carry = (has_obs && !PAD) ? (uint32_t)(((uintptr_t)run0 & 15) / ESZ) : 0u;
     (void)LINE; (void)VEC;
+    if constexpr (PAD) { // the padding elements of the two staged rows: zero, written once (the rows never reach them)
+        const uint32_t npad = pitch - row;
+        if ((uint32_t)lane < npad) {
+            if (OBS16) {
+                reinterpret_cast<uint16_t *>(stage)[row + lane] = 0;
+                reinterpret_cast<uint16_t *>(stage)[pitch + row + lane] = 0;
+            } else {
+                stage[row + lane] = 0.0f;
+                stage[pitch + row + lane] = 0.0f;
+            }
+        }
+    }
     // ---- what happens to one group once its gathers are back: counts / marks, channel values, LDS staging, copy-out
     auto process = [&](const PrcGrp &g, const int j0) __attribute__((always_inline)) {
 #pragma unroll
@@ -650,7 +670,7 @@ k_perceive(const KP p, const float *__restrict__ cells, float *__restrict__ obs,
                     // (POLICY: straight into the workgroup's tile image, row = the ant's index in the tile; a clamped
                     // duplicate of the run's last ant has no row of its own)
                     uint16_t *o16 = POLICY ? tile0 + (uint32_t)prc_tile_ant(wave, min(j0 + u, n_run - 1), run, nwaves) * row + qK
-                                           : reinterpret_cast<uint16_t *>(stage) + carry + (uint32_t)u * row + qK;
+                                           : reinterpret_cast<uint16_t *>(stage) + carry + (uint32_t)u * pitch + qK;
                     o16[0] = bf16_bits(m ? v_ants : -1.0f); o16[1] = bf16_bits(m ? pvs[0] : -1.0f);
                     o16[2] = bf16_bits(m ? pvs[1] : -1.0f); o16[3] = bf16_bits(m ? v_area : -1.0f);
                     o16[4] = bf16_bits(m ? v_wall : -1.0f); o16[5] = bf16_bits(m ? g.fd[u] : -1.0f);
@@ -658,7 +678,7 @@ k_perceive(const KP p, const float *__restrict__ cells, float *__restrict__ obs,
                 } else {
                     // float32: the group's rows are staged back to back behind the carry, as they lie in memory
                     // (the image mirrors the destination modulo one 128-byte line), and flushed together below
-                    float *o = stage + carry + (uint32_t)u * row + qK;
+                    float *o = stage + carry + (uint32_t)u * pitch + qK;
                     o[0] = m ? v_ants : -1.0f; o[1] = m ? pvs[0] : -1.0f; o[2] = m ? pvs[1] : -1.0f;
                     o[3] = m ? v_area : -1.0f; o[4] = m ? v_wall : -1.0f; o[5] = m ? g.fd[u] : -1.0f;
                     if (LAYOUT == PLAYOUT_DEFAULT_ROCKS) o[6] = m ? v_rock : -1.0f;
@@ -673,7 +693,21 @@ k_perceive(const KP p, const float *__restrict__ cells, float *__restrict__ obs,
             // 0.2212 ms last: DESIGN.md, profiles/r03/lines_ab.txt; the code is in profiles/r04/perceive_cleanup.patch.)
             wave_lds_sync();
             const uint32_t rowp = (j0 + 1 < n_run) ? 2u * row : row; // (odd tail of the run: one row)
-            if (OBS16) {
+            if constexpr (PAD) {
+                // whole lines of this wave's own: the image IS the destination, 16-byte piece for piece
+                const uint32_t n16 = ((j0 + 1 < n_run) ? 2u : 1u) * pitch / VEC, last = n16 - 1u;
+                uint4 *d = reinterpret_cast<uint4 *>(reinterpret_cast<unsigned char *>(obs) + ((size_t)e * N + (size_t)PRC_ANT(j0)) * pitch * ESZ);
+                const uint4 *sp = reinterpret_cast<const uint4 *>(stage);
+                const uint32_t i1 = min((uint32_t)lane, last), i2 = min((uint32_t)lane + 64u, last), i3 = min((uint32_t)lane + 128u, last);
+                const uint4 w1 = sp[i1], w2 = sp[i2];
+                uint4 w3 = w2;
+                if (!OBS16) w3 = sp[i3]; // (bfloat16: two rows are at most 96 pieces)
+                if (!abl_store) {
+                    store_stream(d + i1, w1);
+                    store_stream(d + i2, w2);
+                    if (!OBS16) store_stream(d + i3, w3);
+                }
+            } else if (OBS16) {
                 uint16_t *dst16 = reinterpret_cast<uint16_t *>(obs) + ((size_t)e * N + (size_t)PRC_ANT(j0)) * row;
                 const uint32_t mis16 = (uint32_t)(((uintptr_t)dst16 >> 1) & 7);
                 uint16_t *d_al = dst16 - mis16;
@@ -907,36 +941,41 @@ hipError_t antsrl_launch_update_move(const KP &p, int out_buf, double g_dep, dou
     return hipGetLastError();
 }
 
-template <int LAYOUT, bool OBS16, bool ILV, bool HAS_OBS, bool POLICY = false>
+template <int LAYOUT, bool OBS16, bool ILV, bool HAS_OBS, bool POLICY = false, bool PAD = false>
 static hipError_t launch_perceive_t(const KP &p, const float *cells, float *obs, float *agent_state, float *reward,
-                                    int flags, uint32_t seq, hipStream_t st, const PolArgs &pol = PolArgs{})
+                                    int flags, uint32_t seq, hipStream_t st, const PolArgs &pol = PolArgs{}, uint32_t pitch = 0)
 {
     const int run = pick_run(p), nwaves = PRC_TPB / 64;
     if (run < 1 || run > 64) return hipErrorInvalidValue;
     if (POLICY && run * nwaves > 32) return hipErrorInvalidValue; // one MFMA tile of 32 ants per workgroup
     const int nseg = (p.N + run * nwaves - 1) / (run * nwaves);
-    const PrcOff lo = prc_offsets(run, p.PP, p.K, p.R, nwaves, POLICY);
+    const PrcOff lo = prc_offsets(run, p.PP, p.K, p.R, nwaves, POLICY, PAD ? pitch : 0u);
     const size_t pad = PROF_ENV("ANTSRL_PRC_LDS_PAD") ? (size_t)atoi(PROF_ENV("ANTSRL_PRC_LDS_PAD")) * 1024 : 0; // occupancy knob
     size_t lds = lo.total + pad;
     if (POLICY) lds = align_up(lo.total, 16) + 2 * (size_t)prc_policy_img_elems(p.PP * p.K) + 4 * 64 + pad;
     if (lds > 64 * 1024) return hipErrorInvalidValue; // (never with the shapes antsrl_meta_supported admits)
-    hipLaunchKernelGGL((k_perceive<LAYOUT, OBS16, ILV, HAS_OBS, POLICY>), dim3((unsigned)((size_t)p.E * nseg)), dim3(PRC_TPB), lds, st, p,
-                       cells, obs, agent_state, reward, flags, seq, run, nseg, pol);
+    hipLaunchKernelGGL((k_perceive<LAYOUT, OBS16, ILV, HAS_OBS, POLICY, PAD>), dim3((unsigned)((size_t)p.E * nseg)), dim3(PRC_TPB), lds, st, p,
+                       cells, obs, agent_state, reward, flags, seq, run, nseg, pol, pitch);
     return hipGetLastError();
 }
 
 // the in-loop policy needs one tile of at most 32 ants per k_perceive workgroup
 bool antsrl_inloop_policy_supported(const KP &p) { return p.meta && pick_run(p) * (PRC_TPB / 64) <= 32; }
 
+// obs_pitch: elements between two ants' observation rows (antsrl_set_obs_row_stride), 0 = dense
 hipError_t antsrl_launch_perceive(const KP &p, int cur, float *obs, float *agent_state, float *reward, int flags,
-                                  uint32_t seq, hipStream_t st, const PolArgs *pol)
+                                  uint32_t seq, hipStream_t st, const PolArgs *pol, uint32_t obs_pitch)
 {
     const int layout = prc_layout(p);
     const bool o16 = (flags & ACT_OBS_BF16) != 0, ilv = p.ps == 4 && p.fs == 4;
     const float *cells = p.s.phero[cur];
     const bool with_pol = pol && pol->pack && o16; // (the in-loop policy reads bf16 rows: antsrl_set_inloop_policy)
+    const bool padded = obs && obs_pitch != 0 && obs_pitch != (uint32_t)(p.PP * p.K);
+    if (padded && with_pol) return hipErrorNotSupported; // (the tile image the net reads is dense)
 #define PRC_GO(LY)                                                                                             \
     {                                                                                                          \
+        if (padded && o16) return launch_perceive_t<LY, true, ILVV, true, false, true>(p, cells, obs, agent_state, reward, flags, seq, st, PolArgs{}, obs_pitch); \
+        if (padded) return launch_perceive_t<LY, false, ILVV, true, false, true>(p, cells, obs, agent_state, reward, flags, seq, st, PolArgs{}, obs_pitch); \
         if (with_pol && !obs) return launch_perceive_t<LY, true, ILVV, false, true>(p, cells, obs, agent_state, reward, flags, seq, st, *pol); \
         if (!obs) return launch_perceive_t<LY, false, ILVV, false>(p, cells, obs, agent_state, reward, flags, seq, st); \
         if (with_pol) return launch_perceive_t<LY, true, ILVV, true, true>(p, cells, obs, agent_state, reward, flags, seq, st, *pol); \

@@ -374,6 +374,16 @@ int antsrl_bench_copy(void *dst, const void *src, size_t bytes, void *stream);
 #define ANTSRL_OBS_BF16 1
 int antsrl_set_obs_format(AntsHandle *h, int format);
 
+/* Observation row stride (no reference counterpart; opt-in, the default is the dense [E][N][P][P][K] tensor of
+ * RL_api.py:122).  A row of P*P*K values is 1 372 bytes at the reference's 7x7x7 float32 perception: no row starts or ends
+ * on a 128-byte line.  With stride_elems = the row rounded up to whole lines (float32 7x7x7: 352 elements = 1 408 bytes;
+ * bfloat16: 384) the `obs` arguments point to [E][N][stride_elems] buffers (128-byte aligned): element k of ant a's
+ * perception lies at a * stride_elems + k, the padding elements behind it are written as zeros, and every copy-out of
+ * the observation kernel is whole lines of one wave's own.  A torch caller sees the reference's shape through a view:
+ * buf.view(E, N, stride)[..., :P*P*K].view(E, N, P, P, K).  0 (or P*P*K) = dense.  Cell-meta path only
+ * (ANTSRL_Q_CELL_META); not together with antsrl_set_inloop_policy; antsrl_set_obs_format resets it. */
+int antsrl_set_obs_row_stride(AntsHandle *h, int32_t stride_elems);
+
 /* Ants.activate_all_pheromones (environment/ants.py:86-87).  act: float [E][N][C].
  * new_deposit_strength > 0 also changes AntsCfg.deposit_strength (the dtype switch
  * of SURVEY.md §8(a) A4); pass 0 to keep it. */
