@@ -295,6 +295,8 @@ static void fill_kp(const AntsCfg *c, KP *p)
     if (p->meta && p->fs == 1) p->fs = 2;
     // 2 x 4-cell blocks per line for the interleaved records (antsrl_device.h: KP::tiled); ANTSRL_NO_TILED: A/B (profiling build)
     p->tiled = (p->meta && p->ps == 4 && p->fs == 4 && (c->w & 1) == 0 && (c->h & 3) == 0 && !PROF_ENV("ANTSRL_NO_TILED")) ? 1 : 0;
+    // 4 x 4-cell blocks per line for the 8-byte {food, META} records beside separate pheromone buffers (c4's layout: KP::ftile)
+    p->ftile = (p->meta && p->fs == 2 && (c->w & 3) == 0 && (c->h & 3) == 0 && !PROF_ENV("ANTSRL_NO_TILED")) ? 1 : 0;
 }
 
 // f0^S for the next observation, f0^(S+1) for the next deposit

@@ -137,6 +137,10 @@ struct KP {
                       //    ~21 and an ant's old and new cell share a line more often.  Interleaved 16-byte records on the
                       //    cell-meta path only, W even, H a multiple of 4; the bit maps and every canonical (caller-facing)
                       //    layout stay row-major.
+    int32_t ftile;    // 1: the 8-byte {food, META} records of the explicit-sweep layout (fs == 2, cell-meta path) are stored
+                      //    in BLOCKS OF 4 x 4 CELLS per 128-byte line (frec_xy below); the pheromone buffers of that layout
+                      //    stay row-major (the marching stencils stream them).  W and H multiples of 4.
+    int32_t _pad3;
     double g_now;     // f0^S          : materialises values for the perception gather / read-out
     double g_dep;     // f0^(S+1)      : at deposit time, after the conceptual sweep of this update
     double inv_g_dep; // 1 / g_dep

@@ -81,7 +81,7 @@ __device__ __forceinline__ void move_body(const KP &p, const int e, const int8_t
             h_m = STP_LD(p.s.mandibles[a1]);
             if (rotation) h_rot = STP_LD(rotation[a1]);
             if (phero_act) h_pa = STP_LD(phero_act[a1]);
-            h_cprev = rec_xy(p, (int)ppx, (int)ppy); // the RECORD of the previous cell (hash key, food, dirty list)
+            h_cprev = frec_xy(p, (int)ppx, (int)ppy); // the food / META RECORD of the previous cell (hash key, food, dirty list)
             h_q = (UM_ABL & 1) ? 0.0f : food[h_cprev]; // food is first written in phase 1b
         }
     }
@@ -113,7 +113,7 @@ __device__ __forceinline__ void move_body(const KP &p, const int e, const int8_t
                 x = h_x; y = h_y; cprev = h_cprev; q = h_q; old_m = h_m; hold = h_hold;
             } else {
                 x = p.s.x[eN + i]; y = p.s.y[eN + i];
-                cprev = rec_xy(p, (int)p.s.prev_x[eN + i], (int)p.s.prev_y[eN + i]);
+                cprev = frec_xy(p, (int)p.s.prev_x[eN + i], (int)p.s.prev_y[eN + i]);
                 q = food[cprev];
                 old_m = p.s.mandibles[eN + i];
                 hold = p.s.holding[eN + i];
@@ -181,7 +181,7 @@ __device__ __forceinline__ void move_body(const KP &p, const int e, const int8_t
             p.s.theta[eN + i] = th;
         }
         // presence map, RL_api.py:137-141 (0/1, not a count): this observation's number into the cell's stamp
-        const uint32_t cell = rec_xy(p, wrap_index((int)x, W), wrap_index((int)y, H));
+        const uint32_t cell = frec_xy(p, wrap_index((int)x, W), wrap_index((int)y, H));
         // (a plain store: as an nt store k_update_move gains 1 us and k_perceive, whose gathers then miss the line, loses 4:
         //  profiles/r03/ntstamp_ab.txt)
         if (!(UM_ABL & 2) || cell == 0xFFFFFFFFu) pres[(size_t)cell * FS2] = (uint16_t)seq;
@@ -556,9 +556,11 @@ k_perceive(const KP p, const float *__restrict__ cells, float *__restrict__ obs,
     const unsigned long long need_mask = __ballot(own);
     const int src_lane = own ? lane : (need_mask ? __builtin_ctzll(need_mask) : 0);
 
-    // record index of cell (ix, iy): row-major, or blocks of 2 x 4 cells per 128-byte line (KP::tiled, rec_xy in antsrl_util.h)
-    const bool tiled = p.tiled != 0;
-#define PRC_SLOT(ix, iy) (tiled ? tiled_slot((ix), (iy), H) : (uint32_t)((ix) * H + (iy)))
+    // food / META record index of cell (ix, iy) (frec_xy in antsrl_util.h): blocks of 2 x 4 cells per 128-byte line of the
+    // interleaved 16-byte records (KP::tiled: the one gather), blocks of 4 x 4 cells of the 8-byte {food, META} records beside
+    // row-major pheromone buffers (KP::ftile: the second gather; the first one, `pc_`, is row-major), else row-major
+    const bool tiled = p.tiled != 0, ftile = p.ftile != 0;
+#define PRC_SLOT(ix, iy) (tiled ? tiled_slot((ix), (iy), H) : ftile ? tiled44_slot((ix), (iy), H) : (uint32_t)((ix) * H + (iy)))
 #define PRC_LOAD4(ptr) (*reinterpret_cast<const stream_f4 *>(ptr)) // (cached: as nt loads the gathers lose their L1 hits, +5 %)
 #define PRC_FETCH(G0, GRP)                                                                               \
     {                                                                                                    \
@@ -588,7 +590,8 @@ k_perceive(const KP p, const float *__restrict__ cells, float *__restrict__ obs,
                 const stream_f4 t = PRC_LOAD4(ph + (size_t)gc_ * 4);                                     \
                 GRP.pv[u][0] = t.x; GRP.pv[u][1] = t.y; GRP.fd[u] = t.z; GRP.mt[u] = __float_as_uint(t.w); \
             } else {                                                                                     \
-                const float2 t = *reinterpret_cast<const float2 *>(ph + (size_t)gc_ * 2);                \
+                const uint32_t pc_ = abl_gather ? (uint32_t)lane : (uint32_t)__shfl(GRP.ix[u] * H + GRP.iy[u], src_lane); \
+                const float2 t = *reinterpret_cast<const float2 *>(ph + (size_t)pc_ * 2);                \
                 const float2 f = *reinterpret_cast<const float2 *>(fm + (size_t)gc_ * 2);                \
                 GRP.pv[u][0] = t.x; GRP.pv[u][1] = t.y; GRP.fd[u] = f.x; GRP.mt[u] = __float_as_uint(f.y); \
             }                                                                                            \

@@ -69,10 +69,10 @@ __global__ void k_reset_grids(const KP p, const float *__restrict__ food, const 
     const size_t G = (size_t)p.W * p.H, n = (size_t)p.E * G;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const size_t e = i / G, g = i - e * G;
-        const size_t ri = e * G + rec_cell(p, (uint32_t)g); // the cell's record (canonical inputs are row-major)
-        p.s.food[ri * p.fs] = food[i];
+        const size_t ri = e * G + prec_cell(p, (uint32_t)g), fi = e * G + frec_cell(p, (uint32_t)g); // the cell's records (canonical inputs are row-major)
+        p.s.food[fi * p.fs] = food[i];
         if (p.meta) // wall / anthill bits (k_reset_bits ran before on this stream), no ant, never explored
-            reinterpret_cast<uint32_t *>(p.s.food)[ri * p.fs + 1] =
+            reinterpret_cast<uint32_t *>(p.s.food)[fi * p.fs + 1] =
                 (test_bit(p.s.walls_bits + e * p.words, (uint32_t)g) ? META_WALL : 0u) |
                 (test_bit(p.s.area_bits + e * p.words, (uint32_t)g) ? META_AREA : 0u) | (META_NEVER << META_STAMP_SHIFT);
         for (int c = 0; c < p.C; ++c) {
@@ -357,10 +357,10 @@ __global__ void k_gen_cells(const KP p, const AntsGen g, const uint64_t seed)
             }
             if (area) ab |= 1u << b;
             if (wall) wb |= 1u << b;
-            const size_t ri = e * G + rec_xy(p, (int)x, (int)y);
-            p.s.food[ri * p.fs] = (fd && !wall) ? 1.0f : 0.0f;
+            const size_t ri = e * G + prec_xy(p, (int)x, (int)y), fi = e * G + frec_xy(p, (int)x, (int)y);
+            p.s.food[fi * p.fs] = (fd && !wall) ? 1.0f : 0.0f;
             if (p.meta)
-                reinterpret_cast<uint32_t *>(p.s.food)[ri * p.fs + 1] =
+                reinterpret_cast<uint32_t *>(p.s.food)[fi * p.fs + 1] =
                     (wall ? META_WALL : 0u) | (area ? META_AREA : 0u) | (META_NEVER << META_STAMP_SHIFT);
             for (int c = 0; c < p.C; ++c) {
                 p.s.phero[0][ri * p.ps + c] = 0.0f;
@@ -434,7 +434,7 @@ __global__ void k_read_state(const KP p, const int which, const int cur, void *_
     case ANTSRL_S_PHERO: // interleaved [E][G][C] -> canonical [E][C][G]
         for (size_t i = t0; i < EG * p.C; i += stride) {
             const size_t e = i / (G * p.C), rem = i - e * G * p.C, c = rem / G, g = rem - c * G;
-            float v = p.s.phero[cur][(e * G + rec_cell(p, (uint32_t)g)) * p.ps + c];
+            float v = p.s.phero[cur][(e * G + prec_cell(p, (uint32_t)g)) * p.ps + c];
             if (p.scaled) {
                 v *= (float)p.g_now;
                 if (v < (float)p.threshold) v = 0.0f;
@@ -446,7 +446,7 @@ __global__ void k_read_state(const KP p, const int which, const int cur, void *_
         const int c = which - ANTSRL_S_PHERO_C0; // one channel [E][W][H]
         for (size_t i = t0; i < EG; i += stride) {
             const size_t e = i / G;
-            float v = p.s.phero[cur][(e * G + rec_cell(p, (uint32_t)(i - e * G))) * p.ps + c];
+            float v = p.s.phero[cur][(e * G + prec_cell(p, (uint32_t)(i - e * G))) * p.ps + c];
             if (p.scaled) {
                 v *= (float)p.g_now;
                 if (v < (float)p.threshold) v = 0.0f;
@@ -457,7 +457,7 @@ __global__ void k_read_state(const KP p, const int which, const int cur, void *_
     case ANTSRL_S_FOOD:
         for (size_t i = t0; i < EG; i += stride) {
             const size_t e = i / G;
-            ((float *)dstv)[i] = p.s.food[(e * G + rec_cell(p, (uint32_t)(i - e * G))) * p.fs];
+            ((float *)dstv)[i] = p.s.food[(e * G + frec_cell(p, (uint32_t)(i - e * G))) * p.fs];
         }
         break;
     case ANTSRL_S_EXPLORED:
@@ -469,7 +469,7 @@ __global__ void k_read_state(const KP p, const int which, const int cur, void *_
             const uint32_t *m = reinterpret_cast<const uint32_t *>(p.s.food) + 1;
             for (size_t i = t0; i < EG; i += stride) {
                 const size_t e = i / G;
-                ((uint8_t *)dstv)[i] = (uint8_t)((m[(e * G + rec_cell(p, (uint32_t)(i - e * G))) * p.fs] >> META_STAMP_SHIFT) != META_NEVER);
+                ((uint8_t *)dstv)[i] = (uint8_t)((m[(e * G + frec_cell(p, (uint32_t)(i - e * G))) * p.fs] >> META_STAMP_SHIFT) != META_NEVER);
             }
             break;
         }

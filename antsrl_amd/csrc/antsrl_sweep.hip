@@ -133,7 +133,7 @@ __global__ void __launch_bounds__(256) k_phero_wall_clear(const KP p)
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const size_t e = i / G, g = i - e * G;
         if (test_bit(p.s.walls_bits + e * p.words, (uint32_t)g))
-            for (int c = 0; c < p.C; ++c) p.s.phero[0][(e * G + rec_cell(p, (uint32_t)g)) * p.ps + c] = 0.0f;
+            for (int c = 0; c < p.C; ++c) p.s.phero[0][(e * G + prec_cell(p, (uint32_t)g)) * p.ps + c] = 0.0f;
     }
 }
 

@@ -32,7 +32,7 @@ __global__ void __launch_bounds__(256) k_collect_full(const KP p)
     double gain = 0.0;
     for (size_t g = tid; g < G; g += blockDim.x)
         if (test_bit(area, (uint32_t)g)) {
-            const uint32_t r = rec_cell(p, (uint32_t)g);
+            const uint32_t r = frec_cell(p, (uint32_t)g);
             gain += (double)food[r];
             food[r] = 0.0f;
         }

@@ -148,7 +148,7 @@ __device__ __forceinline__ void update_env(const KP &p, const int e, const doubl
         const double x = p.s.x[eN + i], y = p.s.y[eN + i];
         p.s.prev_x[eN + i] = x;
         p.s.prev_y[eN + i] = y;
-        lww_insert(hkeys, hvals, (uint32_t)p.HT - 1, rec_xy(p, (int)x, (int)y), (uint32_t)i); // key: the cell's record index
+        lww_insert(hkeys, hvals, (uint32_t)p.HT - 1, prec_xy(p, (int)x, (int)y), (uint32_t)i); // key: the cell's pheromone record index
         p.s.reward_state[eN + i] = (uint8_t)((double)p.s.reward_state[eN + i] * 0.9); // :130
     }
     __syncthreads();
@@ -167,7 +167,7 @@ __device__ __forceinline__ void update_env(const KP &p, const int e, const doubl
     double gain = 0.0;
     for (int i = tid; i < N; i += T) {
         const uint32_t cell_id = (uint32_t)((int)p.s.x[eN + i] * H + (int)p.s.y[eN + i]); // row-major id: the wall bit map
-        const uint32_t cell = rec_xy(p, (int)p.s.x[eN + i], (int)p.s.y[eN + i]);            // the cell's record
+        const uint32_t cell = prec_xy(p, (int)p.s.x[eN + i], (int)p.s.y[eN + i]);           // the cell's pheromone record
         if (lww_winner(hkeys, hvals, (uint32_t)p.HT - 1, cell) == (uint32_t)i) {
             if (!p.scaled) {
                 for (int c = 0; c < C; ++c) {

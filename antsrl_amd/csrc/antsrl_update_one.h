@@ -157,7 +157,7 @@ __device__ __forceinline__ void update_one_body(const KP &p, const int e, const 
     // ---- Ants.update, ants.py:123-130: prev := cur; deposit (pheromone.py:36-41)
     __syncthreads(); // the hash table is initialised (R == 0 and library jitter: no barrier so far)
     const uint32_t cell_id = (uint32_t)((int)x * H + (int)y); // row-major id: the wall bit map
-    const uint32_t cell = rec_xy(p, (int)x, (int)y);            // the cell's RECORD: deposit, hash key, wall-deposit list
+    const uint32_t cell = prec_xy(p, (int)x, (int)y);           // the cell's PHEROMONE record: deposit, hash key, wall-deposit list
     // the deposit cell's old values, loaded by every ant ahead of the barriers (only the cell's winner uses
     // them; no other ant writes this cell in this update except the wall-deposit clear, and a deposit on a
     // wall cell ignores the old value)

@@ -20,18 +20,30 @@ struct FoodView {
 };
 
 // ------------------------------------------------------------------ cell records
-// Index of cell (x, y) / of row-major cell id `cell` = x * H + y in an environment's cell-record arrays (DState::phero /
-// DState::food under the strides KP::ps / KP::fs).  Row-major, or — KP::tiled — blocks of 2 (x) by 4 (y) cells, block-row
-// major: eight 16-byte records = one 128-byte line per block.
-__device__ __forceinline__ uint32_t rec_xy(const KP &p, const int x, const int y)
+// Index of cell (x, y) / of row-major cell id `cell` = x * H + y in an environment's cell-record arrays under the strides
+// KP::ps / KP::fs: prec_* for the PHEROMONE array (DState::phero), frec_* for the FOOD / META array (DState::food).
+//   interleaved 16-byte records (KP::tiled): ONE array, blocks of 2 (x) by 4 (y) cells per 128-byte line — both the same;
+//   explicit-sweep layout: the pheromone buffers row-major (the stencils march along them), the 8-byte {food, META}
+//   records in blocks of 4 x 4 cells per line (KP::ftile);  everything else row-major.
+__device__ __forceinline__ uint32_t prec_xy(const KP &p, const int x, const int y)
 {
     return p.tiled ? tiled_slot(x, y, p.H) : (uint32_t)(x * p.H + y);
 }
-__device__ __forceinline__ uint32_t rec_cell(const KP &p, const uint32_t cell)
+__device__ __forceinline__ uint32_t frec_xy(const KP &p, const int x, const int y)
+{
+    return p.tiled ? tiled_slot(x, y, p.H) : p.ftile ? tiled44_slot(x, y, p.H) : (uint32_t)(x * p.H + y);
+}
+__device__ __forceinline__ uint32_t prec_cell(const KP &p, const uint32_t cell)
 {
     if (!p.tiled) return cell;
     const uint32_t x = cell / (uint32_t)p.H;
-    return rec_xy(p, (int)x, (int)(cell - x * (uint32_t)p.H));
+    return prec_xy(p, (int)x, (int)(cell - x * (uint32_t)p.H));
+}
+__device__ __forceinline__ uint32_t frec_cell(const KP &p, const uint32_t cell)
+{
+    if (!p.tiled && !p.ftile) return cell;
+    const uint32_t x = cell / (uint32_t)p.H;
+    return frec_xy(p, (int)x, (int)(cell - x * (uint32_t)p.H));
 }
 
 // ------------------------------------------------------------------ small helpers
