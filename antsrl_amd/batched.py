@@ -197,24 +197,29 @@ class BatchedAntsEnv:
         ph = self._dev(self._integral(phero, "pheromone"), torch.int8, (c.n_envs, c.n_ants))
         return rot, ph
 
-    @staticmethod
-    def _integral(a, what):
+    #: check that action arrays hold whole numbers inside int8 before they are cast (one fused device reduction and ONE host
+    #: read per non-int8 device tensor and step); set False in a loop whose actions are known good (e.g. int64 from
+    #: torch.argmax - 1): no host synchronisation is left then.  int8 tensors are never checked (nothing to check).
+    validate_actions = True
+
+    def _integral(self, a, what):
         """Actions are small integers (rotation in {-1, 0, 1} times max_rot_speed, RL_api.py:191; pheromone index in
         {0, 1, 2}, ants.py:90-96) and travel as int8.  ONE rule for numpy arrays, lists and torch tensors (host or
         device): whole numbers of any dtype are accepted, a fractional value or a value outside [-128, 127] raises
-        ValueError — nothing is truncated or wrapped.  int8 tensors skip the check (nothing to check); for other
-        device tensors it costs one small reduction and a host read per call: pass int8 to avoid it."""
+        ValueError — nothing is truncated or wrapped."""
         if a is None:
             return None
         if torch.is_tensor(a):
             if a.dtype == torch.int8 or a.numel() == 0:
                 return a
-            if a.is_floating_point():
-                if not bool(torch.equal(a, a.round())):
+            if self.validate_actions:
+                fl = a.is_floating_point()
+                frac = (a != a.round()).any() if fl else torch.zeros((), dtype=torch.bool, device=a.device)
+                lo, hi, bad = torch.stack([a.min().to(torch.float64), a.max().to(torch.float64), frac.to(torch.float64)]).tolist()
+                if bad:
                     raise ValueError("%s actions must be whole numbers (the kernels take them as int8)" % what)
-            lo, hi = a.min().item(), a.max().item()
-            if lo < -128 or hi > 127:
-                raise ValueError("%s actions out of the int8 range" % what)
+                if lo < -128 or hi > 127:
+                    raise ValueError("%s actions out of the int8 range" % what)
             return a.to(torch.int8) if a.is_floating_point() else a
         arr = np.asarray(a)
         if arr.dtype.kind == "f":

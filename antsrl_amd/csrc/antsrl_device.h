@@ -62,8 +62,17 @@
 #endif
 
 struct __align__(16) AntFrame { double cx, cy, ct, st; }; // perception centre, cos/sin(theta + pi/2)
-// k_update_move: what the update hands to the move of the same ant in registers (x, y after the update = the new `prev`, theta)
-struct UmFwd { double x, y, th; };
+// k_update_move: what the update hands to the move of the same ant in registers — x, y after the update (= the new `prev`)
+// and theta; the food value and META word of the cell the ant stands on (the deposit cell's record IS the record of the
+// move's mandible decision: one 16-byte load instead of a pheromone read, a dependent food read and an area-bit read);
+// and the move's own per-ant inputs, fetched in front of the update so that their round trip rides with the update's.
+struct UmFwd {
+    double x, y, th;
+    float food, hold;
+    uint32_t meta;
+    int m, rot, pa;
+    int rec; // 1: food / meta are valid (interleaved records)
+};
 
 struct DState {
     double *x, *y, *theta, *prev_x, *prev_y; // [E*N]

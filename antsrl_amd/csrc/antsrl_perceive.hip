@@ -70,19 +70,26 @@ __device__ __forceinline__ void move_body(const KP &p, const int e, const int8_t
     if (one) {
         // (k_update_move: the update of the same workgroup has just written x / y / theta and prev := (x, y) of this very ant:
         // handed over in registers — the same values, one memory round trip less in front of the dependent food read)
-        if (fw) {
+        if (fw) { // (k_update_move: no global load at all in front of the move's first barrier)
             h_x = fw->x; h_y = fw->y; h_th = fw->th;
+            h_hold = fw->hold; h_m = fw->m; h_rot = fw->rot; h_pa = fw->pa;
+            h_cprev = frec_xy(p, (int)fw->x, (int)fw->y);
+            // The record was loaded by the update before its anthill collect ran.  Food on the anthill area is all zero once
+            // the collect is done (anthill.py:41-46; the handle only defers an update that needs no full-grid collect), and
+            // nothing else in the update writes food: an area cell reads 0, any other cell what the load returned.
+            if (fw->rec) h_q = (UM_ABL & 1) ? 0.0f : ((fw->meta & META_AREA) ? 0.0f : fw->food);
+            else h_q = (UM_ABL & 1) ? 0.0f : food[h_cprev];
         } else {
             h_x = p.s.x[a1]; h_y = p.s.y[a1]; h_th = p.s.theta[a1];
-        }
-        h_hold = p.s.holding[a1];
-        if (do_step) {
-            const double ppx = fw ? fw->x : STP_LD(p.s.prev_x[a1]), ppy = fw ? fw->y : STP_LD(p.s.prev_y[a1]);
-            h_m = STP_LD(p.s.mandibles[a1]);
-            if (rotation) h_rot = STP_LD(rotation[a1]);
-            if (phero_act) h_pa = STP_LD(phero_act[a1]);
-            h_cprev = frec_xy(p, (int)ppx, (int)ppy); // the food / META RECORD of the previous cell (hash key, food, dirty list)
-            h_q = (UM_ABL & 1) ? 0.0f : food[h_cprev]; // food is first written in phase 1b
+            h_hold = p.s.holding[a1];
+            if (do_step) {
+                const double ppx = STP_LD(p.s.prev_x[a1]), ppy = STP_LD(p.s.prev_y[a1]);
+                h_m = STP_LD(p.s.mandibles[a1]);
+                if (rotation) h_rot = STP_LD(rotation[a1]);
+                if (phero_act) h_pa = STP_LD(phero_act[a1]);
+                h_cprev = frec_xy(p, (int)ppx, (int)ppy); // the food / META RECORD of the previous cell (hash key, food, dirty list)
+                h_q = (UM_ABL & 1) ? 0.0f : food[h_cprev]; // food is first written in phase 1b
+            }
         }
     }
     if (do_step)
@@ -122,7 +129,9 @@ __device__ __forceinline__ void move_body(const KP &p, const int e, const int8_t
             int m = old_m;
             for (int k = 0; k < K; ++k) { // perceived_objects order matters
                 if (p.ch_kind[k] == ANTSRL_CH_FOOD) m = (q > 0.0f) | m;                                // :182
-                else if (p.ch_kind[k] == ANTSRL_CH_ANTHILL) m = (1 - (int)test_bit(area, ccur)) & m;   // :184
+                else if (p.ch_kind[k] == ANTSRL_CH_ANTHILL)                                             // :184
+                    // (k_update_move: the ant still stands where the update left it — the forwarded record's own area bit)
+                    m = (1 - (int)((fw && fw->rec) ? (fw->meta & META_AREA) != 0 : test_bit(area, ccur))) & m;
             }
             const int closing = m & (1 - old_m), opening = (1 - m) & old_m; // ants.py:103-104
             const float taken = fminf((float)p.max_hold, fmaxf(0.0f, q)) * (float)closing; // :111
@@ -210,7 +219,14 @@ k_update_move(const KP p, const int out_buf, const double g_dep, const double in
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const int e = env_of_block(blockIdx.x, p.E, seq);
-    UmFwd fw = {0.0, 0.0, 0.0};
+    UmFwd fw = {};
+    { // the move's own per-ant inputs, ahead of the update: their memory round trip rides with the update's loads
+        const size_t a = (size_t)e * p.N + (threadIdx.x < (unsigned)p.N ? threadIdx.x : 0);
+        fw.hold = p.s.holding[a];
+        fw.m = STP_LD(p.s.mandibles[a]);
+        if (rotation) fw.rot = STP_LD(rotation[a]);
+        if (phero_act) fw.pa = STP_LD(phero_act[a]);
+    }
     update_one_body<C>(p, e, nullptr, out_buf, smem, g_dep, inv_g_dep, &fw);
     __syncthreads(); // the update's global writes are visible to the whole workgroup; its LDS is dead
     move_body<C>(p, e, rotation, phero_act, done, 1, seq, smem, &fw);

@@ -87,9 +87,11 @@ __device__ __forceinline__ void update_one_body(const KP &p, const int e, const 
     if (hit) {
         x = px0;
         y = py0;
-        p.s.theta[a] = theta0 + (u - 0.5); // theta is NOT re-wrapped here
+        if (!fw) p.s.theta[a] = theta0 + (u - 0.5); // theta is NOT re-wrapped here
     }
-    if (fw) fw->th = hit ? theta0 + (u - 0.5) : theta0; // (k_update_move: exactly what the move would load back)
+    // (k_update_move: exactly what the move would load back; the move of the same launch overwrites x / y / theta, so the
+    //  update's own stores of them would be dead)
+    if (fw) fw->th = hit ? theta0 + (u - 0.5) : theta0;
 
     // ---- CircleObstacles.update, circle_obstacles.py:35-58
     if (R > 0) {
@@ -162,10 +164,20 @@ __device__ __forceinline__ void update_one_body(const KP &p, const int e, const 
     // them; no other ant writes this cell in this update except the wall-deposit clear, and a deposit on a
     // wall cell ignores the old value)
     float pold[C];
+    if (fw && p.ps == 4 && C == 2 && !(UM_ABL & 4)) {
+        // interleaved records: the WHOLE record of the cell in one 16-byte load — the move's food value and area bit with it
+        const stream_f4 rec = *reinterpret_cast<const stream_f4 *>(out + (size_t)cell * 4);
+        pold[0] = rec.x;
+        pold[C - 1] = rec.y;
+        fw->food = rec.z;
+        fw->meta = __float_as_uint(rec.w);
+        fw->rec = 1;
+    } else {
 #pragma unroll
-    for (int c = 0; c < C; ++c) pold[c] = (UM_ABL & 4) ? 0.0f : out[(size_t)cell * PS + c]; // (UM_ABL 4: ablation, antsrl_device.h)
+        for (int c = 0; c < C; ++c) pold[c] = (UM_ABL & 4) ? 0.0f : out[(size_t)cell * PS + c]; // (UM_ABL 4: ablation, antsrl_device.h)
+    }
     if (on) {
-        if (moved) {
+        if (moved && !fw) {
             p.s.x[a] = x;
             p.s.y[a] = y;
         }

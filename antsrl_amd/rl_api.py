@@ -66,7 +66,7 @@ class Environment:  # environment/environment.py:21-47
         if self._backend is None:
             return 1
         # every env of a batch steps in lockstep: the library mirrors the counter on the host (no device round trip)
-        ts = self._backend.query(cm.Q_TIMESTEP)
+        ts = self._backend.query(cm.Q_TIMESTEP) + getattr(self, "_host_ts_ahead", 0)
         n = self._backend.cfg.n_envs
         return ts if n == 1 else np.full((n,), ts, dtype=np.int32)
 
@@ -82,11 +82,23 @@ class Environment:  # environment/environment.py:21-47
         by step value between its own objects' updates; a host object cannot run between two phases of one kernel,
         so a step of 0 .. 999 runs after Anthill's 1000 here.  A host object that reads state through the views sees
         the finished update: reads flush a deferred update first.)"""
-        host = [(o.update_step(), i, o) for i, o in enumerate(self.objects) if not getattr(o, "_device_backed", False)]
+        host = [(o.update_step(), i, o) for i, o in enumerate(self.objects) if not _device_updates(o)]
         host.sort(key=lambda t: (t[0], t[1]))  # stable in insertion order, like list.sort(key=update_step)
-        for step, _, o in host:
-            if step < 0:
-                o.update()
+        if any(-1 <= step <= 1000 for step, _, _ in host) and not getattr(self, "_warned_interleave", False):
+            import warnings
+            warnings.warn("a host EnvObject with update_step() between -1 and 1000 runs BEFORE (negative step) or AFTER the "
+                          "whole device update here; the reference interleaves it with Walls (-1) / Rocks, Pheromone (0) / Ants "
+                          "(999) / Anthill (1000) by step and insertion order (environment.py:43-47)")
+            self._warned_interleave = True
+        # (environment.py:45 increments timestep BEFORE any object's update: a host object called in front of the device update
+        #  sees the new value)
+        self._host_ts_ahead = 1
+        try:
+            for step, _, o in host:
+                if step < 0:
+                    o.update()
+        finally:
+            self._host_ts_ahead = 0
         self._backend.update(wall_jitter)
         for step, _, o in host:
             if step >= 0:
@@ -105,6 +117,13 @@ class Environment:  # environment/environment.py:21-47
         for obj in self.objects:
             obj.visualize_copy(snap)  # the snapshot classes register themselves with `snap`
         return snap
+
+
+def _device_updates(obj) -> bool:
+    """True when the backend's kernels do this object's update: a device-backed view whose class has NOT overridden
+    update().  A caller's subclass of a view with its own update() (say a Walls that also moves) is a host object as far
+    as Environment.update is concerned — its update() is called."""
+    return getattr(obj, "_device_backed", False) and type(obj).update is EnvObject.update
 
 
 class _View(EnvObject):

@@ -234,8 +234,10 @@ def test_caller_added_env_objects_are_updated_in_update_step_order():
     t0 = int(np.asarray(env.timestep).reshape(-1)[0])
     env.update()
     assert [c[0] for c in calls] == ["early_b", "early_a", "zero_a", "zero_b", "late"]
-    # timestep += 1 happens inside the device update: the early objects saw the old value, the others the new one
-    assert [c[1] for c in calls] == [t0, t0, t0 + 1, t0 + 1, t0 + 1]
+    # environment.py:45: timestep += 1 BEFORE any object's update — the early objects see the new value too (the device
+    # counter itself moves inside the device update)
+    assert [c[1] for c in calls] == [t0 + 1] * 5
+    assert int(np.asarray(env.timestep).reshape(-1)[0]) == t0 + 1
     # the golden replay is unaffected by host objects (a second, plain env gives the same state)
     api2, env2, _, _ = build("s02_walls")
     api2.observation()
@@ -244,6 +246,38 @@ def test_caller_added_env_objects_are_updated_in_update_step_order():
     np.testing.assert_array_equal(api.ants.ants, api2.ants.ants)
     snap = env.save_state()  # host objects without a visualisation copy add nothing
     assert len(snap.objects) == len(env2.save_state().objects)
+
+
+def test_overridden_view_update_is_called_and_interleaved_steps_warn():
+    """a caller's subclass of a device view with its OWN update() is a host object (its update() is called); a
+    plain view is not (the kernels update it); a host object whose step falls between the device phases warns once."""
+    import warnings
+    from antsrl_amd.rl_api import EnvObject, Walls
+    api, env, F, meta = build("s02_walls")
+    calls = []
+
+    class MovingWalls(Walls):
+        def update(self):
+            calls.append("moving_walls")
+
+    class Mid(EnvObject):
+        def update_step(self):
+            return 500
+
+        def update(self):
+            calls.append("mid")
+
+    MovingWalls(env)
+    Mid(env)
+    api.observation()
+    n = api.ants.n_ants
+    api.step(np.zeros(n, dtype=np.int64), np.ones(n, dtype=np.int64))
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        env.update()
+        env.update()
+    assert calls == ["moving_walls", "mid", "moving_walls", "mid"]  # Walls.update_step() is -1: in front of the device update
+    assert sum("update_step() between" in str(x.message) for x in w) == 1  # once per Environment
 
 
 def test_action_arrays_must_be_whole_numbers_in_int8_range():
@@ -270,3 +304,7 @@ def test_action_arrays_must_be_whole_numbers_in_int8_range():
     for bad in (np.full((2, 8), 300), torch.full((2, 8), 300, dtype=torch.int64), torch.full((2, 8), -200, dtype=torch.int32, device="cuda")):
         with pytest.raises(ValueError):
             env.step(bad, None)
+    # validate_actions = False: no check, no host synchronisation (the caller vouches for its actions)
+    env.validate_actions = False
+    env.reset(synth_init(cfg, seed=1, n_food_discs=2, food_rmin=2, food_rmax=3))
+    assert torch.equal(env.step(torch.ones((2, 8), dtype=torch.int64, device="cuda"), torch.ones((2, 8), dtype=torch.int64, device="cuda"))[0], outs[0])
