@@ -16,9 +16,18 @@ def main():
     import torch
     import torch.distributed as dist
     rank, world, local = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ["LOCAL_RANK"])
+    # ANTSRL_DIST_ONE_GPU=1 (a one-GPU box's rehearsal of world > 1): every rank on device 0, the collective over gloo —
+    # RCCL refuses two ranks on one device.  Everything but the transport is the real thing: the HIP kernels, one process
+    # per rank, shard_cfg's global env ids, ShardedStepper in both modes on device tensors.
+    one_gpu = os.environ.get("ANTSRL_DIST_ONE_GPU") == "1"
+    if one_gpu:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    dist.init_process_group("nccl", device_id=dev)
+    if one_gpu:
+        dist.init_process_group("gloo")
+    else:
+        dist.init_process_group("nccl", device_id=dev)
     from antsrl_amd import config as cm
     from antsrl_amd.batched import BatchedAntsEnv
     from antsrl_amd.dist import RewardGather, ShardedStepper, shard_cfg, shard_range
