@@ -18,6 +18,7 @@ import torch
 
 from . import _lib
 from . import config as cfgmod
+from . import vmm
 from .config import AntsCfg, AntsInit
 
 _STATE_DTYPES = {
@@ -44,13 +45,17 @@ def _ptr(t: Optional[torch.Tensor]):
 
 class BatchedAntsEnv:
     def __init__(self, cfg: AntsCfg, device: Optional[torch.device] = None, obs_dtype: torch.dtype = torch.float32,
-                 obs_row_stride=None):
+                 obs_row_stride=None, pieced_memory: bool = True):
         """obs_dtype: torch.float32 (the reference's values) or torch.bfloat16 (the same values rounded
         to nearest even: half the bytes per step; what the bf16 policy rounds its input to anyway —
         antsrl_set_obs_format).
         obs_row_stride: None (dense, the default) or "line": every ant's row of P*P*K values starts on a 128-byte line
         (antsrl_set_obs_row_stride; float32 7x7x7: 352 elements per row instead of 343).  `self.obs` keeps the reference's
-        shape [E, N, P, P, K] — then as a strided VIEW of `self.obs_padded` [E, N, stride], whose padding is zeros."""
+        shape [E, N, P, P, K] — then as a strided VIEW of `self.obs_padded` [E, N, stride], whose padding is zeros.
+        pieced_memory: the output buffer (the observation tensor) comes from antsrl_mem_alloc (physical pieces of 16 MiB)
+        instead of torch.empty; the workspace stays a torch allocation.  On MI355X the observation kernel runs 15 % apart
+        depending on the physical layout of these two buffers; this combination measured fast on every allocation, two
+        torch allocations mostly slow, two pieced ones in between (antsrl_amd/vmm.py, profiles/r04/placement_probe4*.txt)."""
         if obs_dtype not in (torch.float32, torch.bfloat16):
             raise ValueError("obs_dtype must be torch.float32 or torch.bfloat16")
         if not torch.cuda.is_available():
@@ -64,6 +69,7 @@ class BatchedAntsEnv:
         _lib.check(self.lib.antsrl_workspace_bytes(C.byref(self.cfg), C.byref(need)), "workspace_bytes")
         self.workspace_bytes = need.value
         with torch.cuda.device(self.device):
+            big = (lambda n: vmm.empty_u8(n, self.device)) if pieced_memory else (lambda n: torch.empty(n, dtype=torch.uint8, device=self.device))
             self._ws = torch.empty(need.value + 256, dtype=torch.uint8, device=self.device)
             off = (-self._ws.data_ptr()) % 256
             self._ws_ptr = self._ws.data_ptr() + off
@@ -83,7 +89,7 @@ class BatchedAntsEnv:
             for name, nbytes in sizes:
                 offs[name] = total
                 total += (nbytes + 255) // 256 * 256
-            self._out_flat = torch.zeros((total + 256,), dtype=torch.uint8, device=self.device)
+            self._out_flat = big(total + 256).zero_()
             base = (-self._out_flat.data_ptr()) % 256
             self._out_flat = self._out_flat[base:base + total]
             self._out_offs, self._small_bytes = offs, offs["obs"]

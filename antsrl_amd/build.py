@@ -20,7 +20,7 @@ LIB_PATH = os.path.join(LIB_DIR, "libantsrl_hip.so")
 #: library only (profiles/*.sh, tests/alt_paths.sh load it through ANTSRL_LIB); the product library has none
 PROF_LIB_PATH = os.path.join(LIB_DIR, "libantsrl_hip_prof.so")
 SOURCES = ["antsrl_act.hip", "antsrl_perceive.hip", "antsrl_update.hip", "antsrl_sweep.hip", "antsrl_state.hip",
-           "antsrl_capi.hip", "antsrl_policy.hip"]
+           "antsrl_capi.hip", "antsrl_policy.hip", "antsrl_mem.hip"]
 HEADERS = [os.path.join(CSRC, h) for h in ("antsrl_device.h", "antsrl_util.h", "antsrl_update_env.h",
                                            "antsrl_update_one.h", "antsrl_flush.h", "antsrl_layout.h")] + [
     os.path.join(HERE, "..", "include", "antsrl.h")]

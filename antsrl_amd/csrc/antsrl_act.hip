@@ -436,7 +436,7 @@ k_act(const KP p, const int8_t *__restrict__ rotation, const int8_t *__restrict_
         float c_pv[ACT_UNROLL][C], n_pv[ACT_UNROLL][C], c_fd[ACT_UNROLL], n_fd[ACT_UNROLL];
         // Each wave owns a CONTIGUOUS run of ants, so its observation rows form one sequential write
         // stream: the partial cache line at the end of a row is completed by the same wave's next row
-        // while it is still in L2 (profiles/obs_write_probe.hip: 4.2 -> 4.9 TB/s for this pattern
+        // while it is still in L2 (profiles/history/obs_write_probe.hip: 4.2 -> 4.9 TB/s for this pattern
         // against a run interleaved over the waves).
         const int per = ((N + nwaves - 1) / nwaves + ACT_UNROLL - 1) / ACT_UNROLL * ACT_UNROLL;
         const int i_begin = min(wave * per, N), i_end = min(i_begin + per, N);
@@ -540,7 +540,7 @@ k_act(const KP p, const int8_t *__restrict__ rotation, const int8_t *__restrict_
                 // copy the group out: its rows are contiguous in memory, so the (up to) two rows leave as ONE
                 // run: two 16-byte stores per lane over 128 float4s that start on a 128-byte line (16 whole
                 // lines: streaming stores of whole lines are cheaper than pieces,
-                // profiles/store_policy_probe.hip), a third over the pieces in front of and behind them,
+                // profiles/history/store_policy_probe.hip), a third over the pieces in front of and behind them,
                 // one 4-byte store for the <= 6 edge floats; lanes with nothing left repeat a valid store
                 wave_lds_sync();
                 const uint32_t rowp = (i0 + 1 < i_end) ? 2u * row : row; // (odd tail of the run: one row)
@@ -778,7 +778,7 @@ struct ActPlan {
     bool big; // presence / explored maps in HBM scratch (grids past ~600k cells)
 };
 
-// LDS budget: 160 KiB per CU.  Preference order is MEASURED (c3, MI355X, profiles/plans.sh): the
+// LDS budget: 160 KiB per CU.  Preference order is MEASURED (c3, MI355X, profiles/history/plans.sh): the
 // walls/anthill bitmaps in LDS with two workgroups per CU (0.285 ms) beat the plans that fetch those
 // bits through L1/L2 (0.303 ms; a third workgroup per CU at 80 VGPRs does not raise the CU's
 // throughput either) and one 1024-thread workgroup (0.306-0.315 ms).  So: bitmaps in
@@ -796,7 +796,7 @@ static ActPlan plan_act(const KP &p)
     ActPlan pl{};
     // A batch that leaves half the CUs without a workgroup (E <= CUs / 2) with at least 512 ants per env:
     // one 1024-thread workgroup per env puts twice the waves on the env's perception (c3's envs at
-    // E = 128: k_act 0.052 -> 0.041 ms; at E = 256 it is 6 % slower, profiles/plan_small_e.sh).
+    // E = 128: k_act 0.052 -> 0.041 ms; at E = 256 it is 6 % slower, profiles/history/plan_small_e.sh).
     static const int n_cus = [] {
         int dev = 0, n = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)

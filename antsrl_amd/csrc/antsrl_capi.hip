@@ -154,7 +154,7 @@ static bool use_scaled(const AntsCfg *c)
 
 // Interleaved cell record {p0, p1, food, pad}: with scaled units there is no per-step sweep whose traffic the
 // wider record would inflate, and a perception becomes ONE 16-byte gather per cell instead of an 8-byte
-// and a 4-byte one (profiles/obs_write_probe.hip: 48-57 cycles per ant per CU against 70-77 on L2 hits,
+// and a 4-byte one (profiles/history/obs_write_probe.hip: 48-57 cycles per ant per CU against 70-77 on L2 hits,
 // 180-197 against 275 from HBM).  ANTSRL_NO_INTERLEAVE keeps the separate arrays (A/B).
 static bool use_interleaved(const AntsCfg *c)
 {

@@ -500,7 +500,7 @@ __global__ void k_read_state(const KP p, const int which, const int cur, void *_
 // Measurement helper (antsrl_bench_copy): 16 bytes per lane.  Every 256-thread workgroup copies ONE contiguous
 // 16 KiB chunk (four independent 16-byte loads per lane in flight, then four stores) and workgroups take the
 // chunks in address order: the chip then reads and writes a compact, advancing window, which is what the memory
-// side rewards (profiles/fill_clone_probe.hip: 6.1-6.8 TB/s of writes with 4-16 KiB per workgroup against 4.9-5.3
+// side rewards (profiles/history/fill_clone_probe.hip: 6.1-6.8 TB/s of writes with 4-16 KiB per workgroup against 4.9-5.3
 // with 64 KiB and more).
 __global__ void __launch_bounds__(256) k_copy16(uint4 *__restrict__ dst, const uint4 *__restrict__ src, const size_t n)
 {

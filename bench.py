@@ -423,7 +423,7 @@ def main():
                          perceive="k_perceive", update="k_update_one" if cfg.n_ants <= 1024 else "k_update")
             achieved = ab[dom] * E / (kern[dom] * 1e-3) / 1e9
             # PMC-derived HBM bytes per launch: NOT measured in this run (rocprofv3 --pmc needs its own passes,
-            # profiles/pmc_traffic.sh); the record names the profile it came from
+            # profiles/history/pmc_traffic.sh); the record names the profile it came from
             traffic = traffic_rec.get(names[dom])
             roofline = dict(bound="hbm", kernel=names[dom], achieved=round(achieved, 1), peak=HBM_PEAK_GBS,
                             unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic,

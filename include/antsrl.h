@@ -362,6 +362,19 @@ int antsrl_query(const AntsHandle *h, int what, long long *value);
  * box's achievable read + write bandwidth next to the 8 TB/s specification. */
 int antsrl_bench_copy(void *dst, const void *src, size_t bytes, void *stream);
 
+/* Device memory for the step's big buffers — the workspace and the observation tensor — (no reference counterpart; the
+ * step entry points never allocate: this is an allocator the CALLER may use for the buffers it owns).  The memory is one
+ * virtual range backed by physical pieces of at most ANTSRL_MEM_PIECE_BYTES (hipMemCreate / hipMemMap).  On MI355X the
+ * physical layout of these two buffers is worth 15 % of the observation kernel: when both lie in physically contiguous
+ * ranges of 128 MiB or more (what hipMalloc hands a fresh process) the observation write stream and the cell-record
+ * gathers alias on the memory channels; with either buffer in pieces of at most 32 MiB they do not — k_perceive 0.167 ms
+ * against 0.197 ms at 1024 envs x 512 ants, on every allocation (profiles/r04/placement_probe4*.txt).  The pointer is
+ * aligned to the device's allocation granularity (2 MiB); contents are undefined; free with antsrl_mem_free (never hipFree).  Returns ANTSRL_E_NOMEM
+ * when the device cannot supply the pieces, ANTSRL_E_DEVICE when the runtime lacks the virtual-memory API. */
+#define ANTSRL_MEM_PIECE_BYTES ((size_t)16 << 20)
+int antsrl_mem_alloc(size_t bytes, int device, void **ptr);
+int antsrl_mem_free(void *ptr);
+
 /* Observation tensor format (no reference counterpart: the reference's perception is float64 numpy,
  * cast to float32 by torch.Tensor(state) in the agents, collect_agent_memory.py:194).
  * ANTSRL_OBS_F32 (default): `obs` arguments are float [E][N][P][P][K].

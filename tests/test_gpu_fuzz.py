@@ -193,9 +193,19 @@ def test_random_configuration_library_jitter_no_reads_between_steps(torch_mod, s
             # blocks of 2 x 4 cells (KP::tiled needs W even, H a multiple of 4), the update deferred into k_update_move
             W, H = W & ~1, H & ~3
             kw["filt"], kw["phero_mode"] = np.array([[float(rng.choice([0.999, 0.9]))]]), cm.PHERO_AUTO
+        elif seed % 4 == 1:  # ... a quarter on the explicit-sweep layout with its {food, META} records in blocks of 4 x 4 cells
+            # (KP::ftile needs W and H multiples of 4): a second gather per cell, separate pheromone buffers
+            W, H = max(W & ~3, 12), max(H & ~3, 12)
+            kw["phero_mode"] = cm.PHERO_EXPLICIT_SWEEP
+    # round 4: the shard's global env ids key the library's jitter (AntsCfg.env_id_base) — device and oracle alike —, and a
+    # third of the cell-meta cases write padded observation rows (antsrl_set_obs_row_stride)
+    kw["env_id_base"] = int(rng.integers(0, 1 << 20)) if rng.random() < 0.7 else 0
+    padded = rng.random() < 0.33
     cfg = cm.make_cfg(E, N, W, H, **kw)
     init = synth_init(cfg, seed=seed, n_food_discs=4, food_rmin=1, food_rmax=4, wall_density=0.08)
     env, orc = BatchedAntsEnv(cfg), Oracle(cfg, init)
+    if padded and env.query(cm.Q_CELL_META):
+        env = BatchedAntsEnv(cfg, obs_row_stride="line")
     env.reset(init)
     prev_dist = _anthill_dist(init, orc.ants_xyt)
     for t in range(7):
