@@ -184,3 +184,65 @@ def test_benched_inloop_policy_loop_vs_oracle(want_obs):
                 np.testing.assert_array_equal(got[..., [0, 3, 4, 5]], want[..., [0, 3, 4, 5]])
                 assert np.abs(got[..., 1:3] - want[..., 1:3]).max() <= 2 ** -8
     _final_state_checks(cm, env, orcs, pick, 0)
+
+
+def test_benched_config4_loop_vs_oracle():
+    """configs[3]'s per-GPU shard as bench.py --config c4 runs it (1024 envs x 1024 ants, 512 x 512, radius-3 diffusion):
+    k_sweep_sep2 + k_move + k_perceive + k_update_one every step — explicit-sweep records ({food, META} in 4 x 4-cell blocks,
+    two gathers per cell), the library's wall jitter, no read between steps.  Three environments follow the oracle (a 7 x 7
+    float64 convolution over 2 x 262 144 cells per step: a short horizon)."""
+    import torch
+    from antsrl_amd import config as cm
+    from antsrl_amd.batched import BatchedAntsEnv
+    from antsrl_amd.synth import synth_init
+    from oracle.oracle import Oracle
+    E, N, W, H, steps = 1024, 1024, 512, 512, 24
+    rank, world = 6, 8
+    base = rank * E
+    ax = np.arange(-3, 4)
+    g = np.exp(-(ax[:, None] ** 2 + ax[None, :] ** 2) / 4.5)
+    kw = dict(n_rocks=0, deposit_strength=256.0, max_time=1 << 30, filt=g / g.sum() * (1 - 0.001))  # bench.py's filter
+    cfg = cm.make_cfg(E, N, W, H, env_id_base=base, n_envs_total=world * E, **kw)
+    init = synth_init(cfg, seed=1234, env_offset=base)
+    env = BatchedAntsEnv(cfg)
+    env.reset(init)
+    assert env.query(cm.Q_CELL_META) == 1 and env.query(cm.Q_SCALED_UNITS) == 0 and env.query(cm.Q_FILTER_SEPARABLE) == 1
+    dev = env.device
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(99 + rank)
+    rot = torch.randint(-1, 2, (RING, E, N), generator=gen, device=dev, dtype=torch.int8)
+    ph = torch.randint(0, 3, (RING, E, N), generator=gen, device=dev, dtype=torch.int8)
+    pick = [0, 517, E - 1]
+    pidx = torch.tensor(pick, device=dev)
+    rew_log = torch.empty((steps, len(pick), N), dtype=torch.float32, device=dev)
+    obs_log = {}
+    for t in range(steps):
+        obs, ast, rew, done = env.step_update(rot[t % RING], ph[t % RING], None)
+        rew_log[t] = rew[pidx]
+        if t % 8 == 7:
+            obs_log[t] = obs[pidx].clone()
+    torch.cuda.synchronize(dev)
+    rot_h, ph_h, rew_h = rot[:, pidx].cpu().numpy(), ph[:, pidx].cpu().numpy(), rew_log.cpu().numpy()
+    sub = {k: np.ascontiguousarray(v[pick]) for k, v in init.items()}
+    del init
+    orcs = _oracles(cm, Oracle, kw, N, W, H, {k: v for k, v in sub.items()}, list(range(len(pick))), 0)
+    for j, o in enumerate(orcs):  # (the oracles were built on the sub-batch's rows: give each its GLOBAL env id)
+        o.cfg.env_id_base = base + pick[j]
+    cfg1 = cm.make_cfg(1, N, W, H, **kw)
+    for t in range(steps):
+        for j, o in enumerate(orcs):
+            w = t in obs_log
+            o_obs, _, o_rew, _ = o.step(rot_h[t % RING, j:j + 1], ph_h[t % RING, j:j + 1], want_obs=w)
+            o.update(None)
+            np.testing.assert_array_equal(rew_h[t, j], o_rew[0].astype(np.float32), err_msg="c4 step %d env %d reward" % (t, pick[j]))
+            if w:
+                check_obs(cfg1, obs_log[t][j].cpu().numpy(), o_obs[0], "c4 step %d env %d" % (t, pick[j]))
+    xyt = env.read_state(cm.S_ANTS_XYT)
+    phero, food, expl = env.read_state(cm.S_PHERO), env.read_state(cm.S_FOOD), env.read_state(cm.S_EXPLORED)
+    for j, g_ in enumerate(pick):
+        o = orcs[j]
+        np.testing.assert_allclose(xyt[g_].cpu().numpy(), o.ants_xyt[0], rtol=0, atol=XY_ATOL)
+        np.testing.assert_array_equal(food[g_].cpu().numpy(), o.food[0])
+        np.testing.assert_array_equal(expl[g_].cpu().numpy(), o.explored[0])
+        ok = phero_close(phero[g_].cpu().numpy(), o.phero[0])
+        assert ok.all(), "c4 env %d pheromone: %d cells off" % (g_, (~ok).sum())
