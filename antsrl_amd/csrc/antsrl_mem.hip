@@ -18,17 +18,24 @@
 
 namespace {
 struct Block {
-    size_t size;
+    size_t size, piece;
     std::vector<hipMemGenericAllocationHandle_t> pieces;
 };
 std::mutex g_mu;
 std::unordered_map<void *, Block> g_blocks;
 
-void release(void *base, Block &b, size_t mapped)
+// The physical pieces go back to the device; the VIRTUAL range is never handed out again (`keep_va`: it stays reserved
+// for the life of the process).  On ROCm 7.2 / gfx950 a range that was unmapped, freed and reserved again can still be
+// translated to its OLD physical pieces by the GPU: two live buffers then alias each other's memory — silently
+// (profiles/r04/vmm_stress.py: 95 of 300 allocate / fill / check / free rounds, with one hipMemUnmap per range or one per
+// piece, with the device idle, with 100 ms of waiting).  A virtual address that is never reused cannot meet a stale
+// translation; address space is not a scarce resource (a c3 observation tensor is 0.7 GB of a 128 TB space).
+void release(void *base, Block &b, size_t mapped, bool keep_va)
 {
-    if (mapped) (void)hipMemUnmap(base, mapped);
+    (void)hipDeviceSynchronize();
+    for (size_t off = 0; off < mapped; off += b.piece) (void)hipMemUnmap((char *)base + off, b.piece);
     for (auto h : b.pieces) (void)hipMemRelease(h);
-    if (base) (void)hipMemAddressFree(base, b.size);
+    if (base && !keep_va) (void)hipMemAddressFree(base, b.size);
 }
 } // namespace
 
@@ -53,6 +60,7 @@ extern "C" int antsrl_mem_alloc(size_t bytes, int device, void **ptr)
         const size_t piece = (ANTSRL_MEM_PIECE_BYTES + gran - 1) / gran * gran;
         const size_t n = (bytes + piece - 1) / piece;
         b.size = n * piece;
+        b.piece = piece;
         if (hipMemAddressReserve(&base, b.size, piece, nullptr, 0) != hipSuccess) { base = nullptr; break; }
         bool ok = true;
         for (size_t i = 0; i < n && ok; ++i) {
@@ -70,7 +78,7 @@ extern "C" int antsrl_mem_alloc(size_t bytes, int device, void **ptr)
         rc = ANTSRL_OK;
     } while (false);
     if (rc != ANTSRL_OK) {
-        release(base, b, mapped);
+        release(base, b, mapped, mapped != 0); // (a range that was mapped at all is retired, too)
     } else {
         std::lock_guard<std::mutex> lk(g_mu);
         g_blocks.emplace(base, std::move(b));
@@ -91,6 +99,6 @@ extern "C" int antsrl_mem_free(void *ptr)
         b = std::move(it->second);
         g_blocks.erase(it);
     }
-    release(ptr, b, b.size);
+    release(ptr, b, b.size, true);
     return ANTSRL_OK;
 }

@@ -369,7 +369,9 @@ int antsrl_bench_copy(void *dst, const void *src, size_t bytes, void *stream);
  * ranges of 128 MiB or more (what hipMalloc hands a fresh process) the observation write stream and the cell-record
  * gathers alias on the memory channels; with either buffer in pieces of at most 32 MiB they do not — k_perceive 0.167 ms
  * against 0.197 ms at 1024 envs x 512 ants, on every allocation (profiles/r04/placement_probe4*.txt).  The pointer is
- * aligned to the device's allocation granularity (2 MiB); contents are undefined; free with antsrl_mem_free (never hipFree).  Returns ANTSRL_E_NOMEM
+ * aligned to the device's allocation granularity (2 MiB); contents are undefined; free with antsrl_mem_free (never hipFree):
+ * the physical memory is returned, the virtual range stays reserved for the life of the process (a re-used range can meet
+ * stale GPU translations on ROCm 7.2: antsrl_mem.hip).  Returns ANTSRL_E_NOMEM
  * when the device cannot supply the pieces, ANTSRL_E_DEVICE when the runtime lacks the virtual-memory API. */
 #define ANTSRL_MEM_PIECE_BYTES ((size_t)16 << 20)
 int antsrl_mem_alloc(size_t bytes, int device, void **ptr);

@@ -84,8 +84,9 @@ def test_benched_random_policy_loop_vs_oracle(name, E, N, rocks, age):
     init = synth_init(cfg, seed=1234, env_offset=base)  # bench.py's inputs for this rank
     env = BatchedAntsEnv(cfg)
     env.reset(init)
-    assert env.query(cm.Q_CELL_META) == 1 and env.query(cm.Q_SCALED_UNITS) == 1 and env.query(cm.Q_INTERLEAVED) == 1
-    assert env.query(cm.Q_DEFERRED_UPDATE) == 1, "the benched sequence is k_update_move + k_perceive"
+    if not (env.query(cm.Q_INTERLEAVED) == 1 and env.query(cm.Q_DEFERRED_UPDATE) == 1):
+        pytest.skip("a profiling switch took the handle off the benched path (tests/alt_paths.sh: ANTSRL_NO_INTERLEAVE / ANTSRL_NO_DEFER_UPDATE)")
+    assert env.query(cm.Q_CELL_META) == 1 and env.query(cm.Q_SCALED_UNITS) == 1, "the benched sequence is k_update_move + k_perceive"
     dev = env.device
     g = torch.Generator(device=dev)
     g.manual_seed(99 + rank)
@@ -143,9 +144,12 @@ def test_benched_inloop_policy_loop_vs_oracle(want_obs):
     init = synth_init(cfg, seed=1234, env_offset=base)
     env = BatchedAntsEnv(cfg, obs_dtype=torch.bfloat16)
     env.reset(init)
-    assert env.query(cm.Q_DEFERRED_UPDATE) == 1
+    if env.query(cm.Q_DEFERRED_UPDATE) != 1:
+        pytest.skip("a profiling switch took the handle off the benched path (tests/alt_paths.sh: ANTSRL_NO_DEFER_UPDATE)")
     dev = env.device
     pol = LinearPolicy(cfg.pside * cfg.pside * cfg.n_channels, dev, seed=5 + rank)
+    if env.query(cm.Q_PERCEIVE_RUN) * 4 > 32:
+        pytest.skip("the in-loop policy needs a 32-ant tile per workgroup (tests/alt_paths.sh: ANTSRL_PRC_RUN)")
     pol.attach(env)
     env.observe(want_obs=want_obs)  # main.py:88
     pick = [0, 1, 255, 510, 511]
@@ -206,7 +210,9 @@ def test_benched_config4_loop_vs_oracle():
     init = synth_init(cfg, seed=1234, env_offset=base)
     env = BatchedAntsEnv(cfg)
     env.reset(init)
-    assert env.query(cm.Q_CELL_META) == 1 and env.query(cm.Q_SCALED_UNITS) == 0 and env.query(cm.Q_FILTER_SEPARABLE) == 1
+    assert env.query(cm.Q_CELL_META) == 1 and env.query(cm.Q_SCALED_UNITS) == 0
+    if env.query(cm.Q_FILTER_SEPARABLE) != 1:
+        pytest.skip("a profiling switch took the separable stencil away (tests/alt_paths.sh: ANTSRL_NO_SEPARABLE)")
     dev = env.device
     gen = torch.Generator(device=dev)
     gen.manual_seed(99 + rank)

@@ -52,3 +52,26 @@ def test_env_on_pieced_memory_equals_env_on_torch_memory():
             assert torch.equal(x, y)
     for which in (cm.S_ANTS_XYT, cm.S_PHERO, cm.S_FOOD, cm.S_EXPLORED):
         assert torch.equal(a.read_state(which), b.read_state(which))
+
+
+def test_freed_ranges_never_alias_live_buffers():
+    """antsrl_mem_free retires the virtual range (antsrl_mem.hip): on ROCm 7.2 a re-used range could still be translated to
+    its OLD physical pieces, so that two live buffers aliased each other — seen in 95 of 300 rounds of exactly this loop
+    before the fix (profiles/r04/vmm_stress.py).  Allocate two buffers, fill, cross-copy, check, free; sizes vary."""
+    import torch
+    from antsrl_amd import vmm
+    seen = set()
+    for it in range(60):
+        n = ((it % 7) * 37 + 70) << 20
+        v = vmm.pieced_u8(n, "cuda:0").view(torch.int32)
+        assert v.data_ptr() not in seen, "a virtual range was handed out twice"
+        seen.add(v.data_ptr())
+        v.fill_(it + 1)
+        other = torch.empty(n // 4, dtype=torch.int32, device="cuda:0").fill_(-(it + 1))
+        u = vmm.pieced_u8(n, "cuda:0").view(torch.int32)
+        u.copy_(v)
+        u += 1000000
+        assert bool((v == it + 1).all()) and bool((u == it + 1 + 1000000).all()) and bool((other == -(it + 1)).all()), it
+        del v, u, other
+        if it % 3 == 0:
+            gc.collect()
