@@ -72,6 +72,8 @@ def test_row_stride_is_validated_and_excludes_the_inloop_policy():
     kact = BatchedAntsEnv(cm.make_cfg(4, 64, 64, 64, n_rocks=2, act_path=cm.ACT_SINGLE_KERNEL))
     assert lib.antsrl_set_obs_row_stride(kact._h, 352) == -4  # cell-meta path only
     p16 = BatchedAntsEnv(cfg, obs_dtype=torch.bfloat16, obs_row_stride="line")
+    if p16.query(cm.Q_PERCEIVE_RUN) * 4 > 32:
+        pytest.skip("the in-loop policy needs a 32-ant tile per workgroup (tests/alt_paths.sh: ANTSRL_PRC_RUN)")
     p16.reset(synth_init(cfg, seed=1, n_food_discs=3, food_rmin=2, food_rmax=4))
     LinearPolicy(cfg.pside ** 2 * cfg.n_channels, p16.device, seed=1).attach(p16)
     with pytest.raises(_lib.AntsrlError, match="in-loop policy"):
