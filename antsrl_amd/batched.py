@@ -77,8 +77,6 @@ class BatchedAntsEnv:
             _lib.check(self.lib.antsrl_create(C.byref(self.cfg), C.c_void_p(self._ws_ptr), need.value,
                                               C.byref(self._h)), "create")
             E, N, P, K = cfg.n_envs, cfg.n_ants, cfg.pside, cfg.n_channels
-            # The four step outputs are views of ONE device buffer (256-byte aligned pieces, the small ones
-            # first): outputs_to_host() brings them over in a single copy.
             esz = 4 if obs_dtype == torch.float32 else 2
             row = P * P * K
             if obs_row_stride not in (None, "line"):
@@ -89,26 +87,14 @@ class BatchedAntsEnv:
             for name, nbytes in sizes:
                 offs[name] = total
                 total += (nbytes + 255) // 256 * 256
-            self._out_flat = big(total + 256).zero_()
-            base = (-self._out_flat.data_ptr()) % 256
-            self._out_flat = self._out_flat[base:base + total]
-            self._out_offs, self._small_bytes = offs, offs["obs"]
-
-            def piece(name, nbytes, dtype, shape):
-                return self._out_flat[offs[name]:offs[name] + nbytes].view(dtype).view(shape)
+            self._out_sizes, self._out_offs, self._out_total, self._small_bytes = sizes, offs, total, offs["obs"]
+            self._obs_dtype, self._obs_pitch_row = obs_dtype, (pitch, row)
             if obs_dtype == torch.bfloat16:
                 _lib.check(self.lib.antsrl_set_obs_format(self._h, 1), "set_obs_format")
-            if pitch == row:
-                self.obs = piece("obs", sizes[3][1], obs_dtype, (E, N, P, P, K))
-                self.obs_padded = None
-            else:  # rows a whole number of 128-byte lines apart; the reference's shape is a view of the padded buffer
-                self.obs_padded = piece("obs", sizes[3][1], obs_dtype, (E, N, pitch))
-                self.obs = self.obs_padded[..., :row].unflatten(-1, (P, P, K))
+            if pitch != row:
                 _lib.check(self.lib.antsrl_set_obs_row_stride(self._h, pitch), "set_obs_row_stride")
             self.obs_row_pitch = pitch
-            self.agent_state = piece("agent_state", sizes[0][1], torch.float32, (E, N, 2))
-            self.reward = piece("reward", sizes[1][1], torch.float32, (E, N))
-            self.done = piece("done", sizes[2][1], torch.uint8, (E,))
+            self._bind_outputs(big(total + 256).zero_())
         self._keep = None
         self._host_out = None   # pinned mirror of _out_flat (outputs_to_host)
         self._host_act = None   # pinned staging of numpy actions + the event of its last upload
@@ -121,6 +107,80 @@ class BatchedAntsEnv:
             self._h = None
 
     # ------------------------------------------------------------------ helpers
+    def _bind_outputs(self, flat: torch.Tensor) -> None:
+        """The four step outputs as views of ONE device buffer `flat` (256-byte aligned pieces, the small ones first):
+        outputs_to_host() brings them over in a single copy."""
+        c = self.cfg
+        E, N, P, K = c.n_envs, c.n_ants, c.pside, c.n_channels
+        sizes, offs, total = self._out_sizes, self._out_offs, self._out_total
+        pitch, row = self._obs_pitch_row
+        base = (-flat.data_ptr()) % 256
+        self._out_flat = flat[base:base + total]
+
+        def piece(name, nbytes, dtype, shape):
+            return self._out_flat[offs[name]:offs[name] + nbytes].view(dtype).view(shape)
+        if pitch == row:
+            self.obs = piece("obs", sizes[3][1], self._obs_dtype, (E, N, P, P, K))
+            self.obs_padded = None
+        else:  # rows a whole number of 128-byte lines apart; the reference's shape is a view of the padded buffer
+            self.obs_padded = piece("obs", sizes[3][1], self._obs_dtype, (E, N, pitch))
+            self.obs = self.obs_padded[..., :row].unflatten(-1, (P, P, K))
+        self.agent_state = piece("agent_state", sizes[0][1], torch.float32, (E, N, 2))
+        self.reward = piece("reward", sizes[1][1], torch.float32, (E, N))
+        self.done = piece("done", sizes[2][1], torch.uint8, (E,))
+        self._host_out = None
+
+    def tune_placement(self, trials: int = 4, age: int = 150, steps: int = 30, verbose: bool = False):
+        """Pick the output buffer whose PHYSICAL placement steps fastest — call it BEFORE reset() / generate(): it runs a
+        scratch episode on the handle (device generator + uniform random actions) and leaves the handle to be reset.
+
+        Why: on MI355X the observation kernel runs up to 15 % apart depending on where the observation tensor and the
+        workspace lie in physical memory.  Pieced memory (antsrl_mem_alloc) makes the fast case the
+        usual one, not the certain one: the first process on a fresh box still lands on the slow side now and then
+        (profiles/r04/bench_default_first_process.json).  So: up to `trials` candidate buffers (the current one, then
+        alternately torch.empty and pieced memory), `steps` steps each at the same point of the same scratch episode, keep
+        the fastest, free the rest.  One-off cost ~0.1 s at c3.  Returns the per-candidate ms/step (None for small batches,
+        where there is nothing to alias)."""
+        if self._out_total < vmm.SMALL_BYTES or trials < 2:
+            return None
+        c = self.cfg
+        E, N = c.n_envs, c.n_ants
+        with torch.cuda.device(self.device):
+            self.generate(cfgmod.make_gen(), episode_seed=0x7A11)
+            g = torch.Generator(device=self.device)
+            g.manual_seed(7)
+            rot = torch.randint(-1, 2, (4, E, N), generator=g, device=self.device, dtype=torch.int8)
+            ph = torch.randint(0, 3, (4, E, N), generator=g, device=self.device, dtype=torch.int8) if c.n_phero == 2 else [None] * 4
+            for t in range(age):
+                self.step_update(rot[t % 4], ph[t % 4], None)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+            def measure():
+                for t in range(4):
+                    self.step_update(rot[t % 4], ph[t % 4], None)
+                e0.record()
+                for t in range(steps):
+                    self.step_update(rot[t % 4], ph[t % 4], None)
+                e1.record()
+                e1.synchronize()
+                return e0.elapsed_time(e1) / steps
+            cands = [self._out_flat]
+            times = [measure()]
+            for i in range(1, trials):
+                n = self._out_total + 256
+                buf = (torch.empty(n, dtype=torch.uint8, device=self.device) if i % 2 else vmm.empty_u8(n, self.device)).zero_()
+                self._bind_outputs(buf)
+                cands.append(buf)
+                times.append(measure())
+            best = min(range(len(times)), key=times.__getitem__)
+            if verbose:
+                print("tune_placement: ms/step per candidate %s -> %d" % (["%.4f" % t for t in times], best))
+            self._bind_outputs(cands[best])
+            del cands
+            self._out_flat.zero_()
+        self.placement_trials = dict(ms_per_step=[round(t, 5) for t in times], chosen=best)
+        return times
+
     @property
     def _obs_buf(self):
         """The tensor whose address the kernels get: `obs` itself (a caller may re-point it, like reward / done), or the

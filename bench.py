@@ -204,6 +204,10 @@ def main():
     ap.add_argument("--obs-row-stride", default=None, choices=["line"],
                     help="opt-in: observation rows a whole number of 128-byte lines apart (antsrl_set_obs_row_stride; measured 8 %% "
                          "SLOWER on c3: profiles/r04/obs_stride_ab_c3.txt) — the default and the headline are the dense tensor")
+    ap.add_argument("--no-tune-placement", action="store_true",
+                    help="skip BatchedAntsEnv.tune_placement(): by default, before the episode is loaded, up to 4 candidate output "
+                         "buffers are stepped on a scratch episode and the fastest physical placement is kept (~0.1 s, outside "
+                         "every timed region; DESIGN.md section 2)")
     ap.add_argument("--no-obs", action="store_true",
                     help="--policy mlp, in-loop: act-only rollout (collect_agent_memory.py:189-199 with training=False) — no "
                          "observation tensor is written, the rows feed the net from LDS; rewards / agent_state / done are")
@@ -273,6 +277,7 @@ def main():
     policy_kind = args.policy or W_.get("policy", "random")
     obs_dtype = args.obs_dtype or ("bf16" if policy_kind == "mlp" else "f32")
     env = BatchedAntsEnv(cfg, dev, obs_dtype=torch.bfloat16 if obs_dtype == "bf16" else torch.float32, obs_row_stride=args.obs_row_stride)
+    placement = None if args.no_tune_placement else env.tune_placement()  # (a scratch episode; the real one is loaded next)
     env.reset(synth_init(cfg, seed=1234, env_offset=rank * E))
     RING = 8
     g = torch.Generator(device=dev)
@@ -466,7 +471,8 @@ def main():
                        "pheromone_channels": cfg.n_phero, "rocks": cfg.n_rocks, "obs_channels": cfg.n_channels,
                        "filter_radius": cfg.filter_radius,
                        "filter_separable": bool(env.query(cm.Q_FILTER_SEPARABLE)) if cfg.filter_radius else None,
-                       "obs_row_pitch_elems": env.obs_row_pitch, "reward": "ExplorationReward", "obs_dtype": obs_dtype if want_obs else "none (act-only: rows stay in LDS)",
+                       "obs_row_pitch_elems": env.obs_row_pitch,
+                       "placement_trials_ms_per_step": (getattr(env, "placement_trials", None) if placement else None), "reward": "ExplorationReward", "obs_dtype": obs_dtype if want_obs else "none (act-only: rows stay in LDS)",
                        "pheromone_update": "scaled units (no per-step sweep)" if scaled else "explicit sweep kernel",
                        "kernels": ("k_update_move (the previous step's update + this step's move, one launch) + k_perceive "
                                    "(cell-meta layout, %d ants per wave)" % env.query(cm.Q_PERCEIVE_RUN)) if meta_path and deferred

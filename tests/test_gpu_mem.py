@@ -24,10 +24,13 @@ def test_pieced_memory_round_trip_and_lifetime():
     del t, v
     gc.collect()
     assert int(w[-1]) == 7
-    del w                    # ... the last one releases it
+    torch.cuda.synchronize()
+    held = torch.cuda.mem_get_info()[0]
+    del w                    # ... the last one releases it: the physical pieces go back to the device
     gc.collect()
     torch.cuda.synchronize()
-    assert torch.cuda.mem_get_info()[0] >= free0 - (32 << 20)  # (nothing of the 200 MiB is still held)
+    assert torch.cuda.mem_get_info()[0] - held >= (190 << 20), "the 200 MiB were not returned"
+    del free0
     # the C-ABI directly: bad arguments, double free
     p = C.c_void_p()
     assert lib.antsrl_mem_alloc(0, 0, C.byref(p)) == -1
@@ -75,3 +78,29 @@ def test_freed_ranges_never_alias_live_buffers():
         del v, u, other
         if it % 3 == 0:
             gc.collect()
+
+
+def test_tune_placement_leaves_a_clean_handle():
+    """BatchedAntsEnv.tune_placement() steps a scratch episode on candidate output buffers and keeps the fastest; the handle
+    is then loaded as usual — results equal those of an env that never tuned, whatever buffer won."""
+    import torch
+    from antsrl_amd import config as cm
+    from antsrl_amd.batched import BatchedAntsEnv
+    from antsrl_amd.synth import random_actions, synth_init
+    cfg = cm.make_cfg(128, 384, 256, 256, n_rocks=4, deposit_strength=256.0)
+    init = synth_init(cfg, seed=3)
+    a, b = BatchedAntsEnv(cfg), BatchedAntsEnv(cfg)
+    times = a.tune_placement(trials=3, age=20, steps=8)
+    assert times is not None and len(times) == 3 and a.placement_trials["chosen"] in (0, 1, 2)
+    assert BatchedAntsEnv(cm.make_cfg(2, 8, 32, 32)).tune_placement() is None  # (small batches: nothing to alias)
+    a.reset(init)
+    b.reset(init)
+    rot, ph = random_actions(cfg, 5, seed=2)
+    for t in range(5):
+        for x, y in zip(a.step_update(rot[t], ph[t], None), b.step_update(rot[t], ph[t], None)):
+            assert torch.equal(x, y)
+    ha, hb = a.outputs_to_host(), b.outputs_to_host()
+    for x, y in zip(ha, hb):
+        assert (x == y).all()
+    for which in (cm.S_ANTS_XYT, cm.S_PHERO, cm.S_FOOD, cm.S_EXPLORED, cm.S_TIMESTEP):
+        assert torch.equal(a.read_state(which), b.read_state(which))
