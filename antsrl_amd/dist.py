@@ -6,7 +6,10 @@ process per GPU, all state resident on its GPU for the whole episode: no halo, n
 data-path collective.  The ONLY exchange is the all-gather of reward[E_local, N] (fp32) and
 done[E_local] (u8) each step, so that every rank / the host sees the full batch.
 
-Backend "nccl" is RCCL on ROCm (over xGMI inside a node); "gloo" is used by the CPU tests.
+Backend "nccl" is RCCL on ROCm (over xGMI inside a node); "gloo" is used by the CPU tests and by the one-GPU rehearsal of
+world > 1 (tests/test_a_gpu_dist.py).  Set TORCH_NCCL_HIGH_PRIORITY=1 before init_process_group (bench.py does): on RCCL's
+default-priority stream the per-step gather shares a hardware queue with the step's kernels and costs +41 us per 0.24 ms step
+(one rank, measured: profiles/r04/dist_overhead_ab.txt); on a high-priority stream +4 us.
 
 The gather is ONE collective per step: reward and done travel in a single fused fp32 buffer
 [E_local, N+1] (done in the last column — xGMI all-gathers of this size are latency-bound, so one

@@ -64,13 +64,15 @@ def test_worker_runs_with_one_rank():
     assert "DIST_GPU_OK 0 of 1" in out.stdout, out.stdout[-4000:]
 
 
-def test_two_ranks_on_one_gpu_over_gloo():
-    """A one-GPU box's rehearsal of world > 1 (RCCL refuses two ranks on one device, so the transport is gloo): two processes,
-    each with its own handle on the same GPU, every shard carrying its global env ids, both gather modes on device tensors,
-    every gathered step compared with the single-rank run of the whole batch — bit for bit."""
+@pytest.mark.parametrize("world", [2, 3])
+def test_ranks_on_one_gpu_over_gloo(world):
+    """A one-GPU box's rehearsal of world > 1 (RCCL refuses two ranks on one device, so the transport is gloo): `world`
+    processes, each with its own handle on the same GPU, every shard carrying its global env ids (ragged blocks: 6 * world + 1
+    environments), both gather modes on device tensors, every gathered step compared with the single-rank run of the whole
+    batch — bit for bit."""
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", ANTSRL_DIST_ONE_GPU="1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "dist_gpu_worker.py")]
     out = _run(cmd, env)
     assert out.returncode == 0, out.stdout[-6000:]
-    assert all("DIST_GPU_OK %d of 2" % r in out.stdout for r in range(2)), out.stdout[-4000:]
+    assert all("DIST_GPU_OK %d of %d" % (r, world) in out.stdout for r in range(world)), out.stdout[-4000:]
