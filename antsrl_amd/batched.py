@@ -70,12 +70,9 @@ class BatchedAntsEnv:
         self.workspace_bytes = need.value
         with torch.cuda.device(self.device):
             big = (lambda n: vmm.empty_u8(n, self.device)) if pieced_memory else (lambda n: torch.empty(n, dtype=torch.uint8, device=self.device))
-            self._ws = torch.empty(need.value + 256, dtype=torch.uint8, device=self.device)
-            off = (-self._ws.data_ptr()) % 256
-            self._ws_ptr = self._ws.data_ptr() + off
-            self._h = C.c_void_p()
-            _lib.check(self.lib.antsrl_create(C.byref(self.cfg), C.c_void_p(self._ws_ptr), need.value,
-                                              C.byref(self._h)), "create")
+            self._pieced = bool(pieced_memory)
+            self._h = None
+            self._make_handle(torch.empty(need.value + 256, dtype=torch.uint8, device=self.device))
             E, N, P, K = cfg.n_envs, cfg.n_ants, cfg.pside, cfg.n_channels
             esz = 4 if obs_dtype == torch.float32 else 2
             row = P * P * K
@@ -130,30 +127,50 @@ class BatchedAntsEnv:
         self.done = piece("done", sizes[2][1], torch.uint8, (E,))
         self._host_out = None
 
-    def tune_placement(self, trials: int = 4, age: int = 150, steps: int = 30, verbose: bool = False):
-        """Pick the output buffer whose PHYSICAL placement steps fastest — call it BEFORE reset() / generate(): it runs a
-        scratch episode on the handle (device generator + uniform random actions) and leaves the handle to be reset.
+    def _make_handle(self, ws: torch.Tensor) -> None:
+        """(Re)creates the handle over workspace tensor `ws` with this env's configuration and observation format."""
+        if getattr(self, "_h", None):
+            self.lib.antsrl_destroy(self._h)
+        self._ws = ws
+        self._ws_ptr = ws.data_ptr() + (-ws.data_ptr()) % 256
+        self._h = C.c_void_p()
+        _lib.check(self.lib.antsrl_create(C.byref(self.cfg), C.c_void_p(self._ws_ptr), self.workspace_bytes, C.byref(self._h)), "create")
+        if getattr(self, "_obs_dtype", torch.float32) == torch.bfloat16:
+            _lib.check(self.lib.antsrl_set_obs_format(self._h, 1), "set_obs_format")
+        pitch, row = getattr(self, "_obs_pitch_row", (0, 0))
+        if pitch != row:
+            _lib.check(self.lib.antsrl_set_obs_row_stride(self._h, pitch), "set_obs_row_stride")
+
+    def tune_placement(self, age: int = 150, steps: int = 30, verbose: bool = False):
+        """Pick the (workspace, output buffer) pair whose PHYSICAL placement steps fastest.  Call it right after construction,
+        BEFORE reset() / generate() and before anything is attached to the handle: it runs scratch episodes (device
+        generator + uniform random actions), may re-create the handle on another workspace, and leaves it to be reset.
 
         Why: on MI355X the observation kernel runs up to 15 % apart depending on where the observation tensor and the
-        workspace lie in physical memory.  Pieced memory (antsrl_mem_alloc) makes the fast case the
-        usual one, not the certain one: the first process on a fresh box still lands on the slow side now and then
-        (profiles/r04/bench_default_first_process.json).  So: up to `trials` candidate buffers (the current one, then
-        alternately torch.empty and pieced memory), `steps` steps each at the same point of the same scratch episode, keep
-        the fastest, free the rest.  One-off cost ~0.1 s at c3.  Returns the per-candidate ms/step (None for small batches,
-        where there is nothing to alias)."""
-        if self._out_total < vmm.SMALL_BYTES or trials < 2:
+        workspace lie in physical memory: two hipMalloc ranges are usually the slow pair, one of the two
+        on antsrl_mem_alloc pieces usually a fast one — usually, and which of the two depends on the box.  So the four
+        combinations {torch.empty, pieced} x {torch.empty, pieced} are each stepped `steps` times at the same point of the same
+        scratch episode and the fastest pair is kept; the others are freed.  One-off cost ~0.2 s at c3.  Returns the four
+        ms/step figures (None for small batches, where there is nothing to alias)."""
+        if self._out_total < vmm.SMALL_BYTES:
             return None
         c = self.cfg
         E, N = c.n_envs, c.n_ants
-        with torch.cuda.device(self.device):
-            self.generate(cfgmod.make_gen(), episode_seed=0x7A11)
-            g = torch.Generator(device=self.device)
+        dev = self.device
+
+        def torch_u8(n):
+            return torch.empty(n, dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            g = torch.Generator(device=dev)
             g.manual_seed(7)
-            rot = torch.randint(-1, 2, (4, E, N), generator=g, device=self.device, dtype=torch.int8)
-            ph = torch.randint(0, 3, (4, E, N), generator=g, device=self.device, dtype=torch.int8) if c.n_phero == 2 else [None] * 4
-            for t in range(age):
-                self.step_update(rot[t % 4], ph[t % 4], None)
+            rot = torch.randint(-1, 2, (4, E, N), generator=g, device=dev, dtype=torch.int8)
+            ph = torch.randint(0, 3, (4, E, N), generator=g, device=dev, dtype=torch.int8) if c.n_phero == 2 else [None] * 4
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+            def scratch_episode():
+                self.generate(cfgmod.make_gen(), episode_seed=0x7A11)
+                for t in range(age):
+                    self.step_update(rot[t % 4], ph[t % 4], None)
 
             def measure():
                 for t in range(4):
@@ -164,21 +181,36 @@ class BatchedAntsEnv:
                 e1.record()
                 e1.synchronize()
                 return e0.elapsed_time(e1) / steps
-            cands = [self._out_flat]
-            times = [measure()]
-            for i in range(1, trials):
-                n = self._out_total + 256
-                buf = (torch.empty(n, dtype=torch.uint8, device=self.device) if i % 2 else vmm.empty_u8(n, self.device)).zero_()
-                self._bind_outputs(buf)
-                cands.append(buf)
-                times.append(measure())
-            best = min(range(len(times)), key=times.__getitem__)
+            # the env's own pair first (workspace torch.empty, outputs pieced unless pieced_memory=False), then the other three
+            own_ws, own_out = self._ws, self._out_flat
+            n_ws, n_out = self.workspace_bytes + 256, self._out_total + 256
+            pairs, times = [], []
+            for ws_kind in ("own", "other"):
+                if ws_kind == "other":
+                    self._make_handle(vmm.empty_u8(n_ws, dev))  # (the env's own workspace is torch.empty memory)
+                scratch_episode()
+                for out_kind in ("own", "other"):
+                    if out_kind == "other":
+                        self._bind_outputs((torch_u8(n_out) if self._pieced else vmm.empty_u8(n_out, dev)).zero_())
+                    elif ws_kind == "other":
+                        self._bind_outputs(own_out)
+                    pairs.append((self._ws, self._out_flat))
+                    times.append(measure())
+            best = min(range(4), key=times.__getitem__)
             if verbose:
-                print("tune_placement: ms/step per candidate %s -> %d" % (["%.4f" % t for t in times], best))
-            self._bind_outputs(cands[best])
-            del cands
+                print("tune_placement: ms/step per (workspace, outputs) pair %s -> %d" % (["%.4f" % t for t in times], best))
+            ws, out = pairs[best]
+            del pairs
+            if ws.data_ptr() != self._ws.data_ptr():
+                self._make_handle(ws)
+            self._bind_outputs(out)
             self._out_flat.zero_()
-        self.placement_trials = dict(ms_per_step=[round(t, 5) for t in times], chosen=best)
+            del own_ws, own_out, ws, out
+        self.placement_trials = dict(ms_per_step=[round(t, 5) for t in times], chosen=best,
+                                     pairs=["ws torch / out %s" % ("pieced" if self._pieced else "torch"),
+                                            "ws torch / out %s" % ("torch" if self._pieced else "pieced"),
+                                            "ws pieced / out %s" % ("pieced" if self._pieced else "torch"),
+                                            "ws pieced / out %s" % ("torch" if self._pieced else "pieced")])
         return times
 
     @property

@@ -81,8 +81,9 @@ def test_freed_ranges_never_alias_live_buffers():
 
 
 def test_tune_placement_leaves_a_clean_handle():
-    """BatchedAntsEnv.tune_placement() steps a scratch episode on candidate output buffers and keeps the fastest; the handle
-    is then loaded as usual — results equal those of an env that never tuned, whatever buffer won."""
+    """BatchedAntsEnv.tune_placement() steps scratch episodes on the four {torch, pieced} x {torch, pieced} (workspace, outputs)
+    pairs and keeps the fastest (possibly a re-created handle on another workspace); the handle is then loaded as usual —
+    results equal those of an env that never tuned, whatever pair won."""
     import torch
     from antsrl_amd import config as cm
     from antsrl_amd.batched import BatchedAntsEnv
@@ -90,8 +91,8 @@ def test_tune_placement_leaves_a_clean_handle():
     cfg = cm.make_cfg(128, 384, 256, 256, n_rocks=4, deposit_strength=256.0)
     init = synth_init(cfg, seed=3)
     a, b = BatchedAntsEnv(cfg), BatchedAntsEnv(cfg)
-    times = a.tune_placement(trials=3, age=20, steps=8)
-    assert times is not None and len(times) == 3 and a.placement_trials["chosen"] in (0, 1, 2)
+    times = a.tune_placement(age=20, steps=8)
+    assert times is not None and len(times) == 4 and a.placement_trials["chosen"] in (0, 1, 2, 3)
     assert BatchedAntsEnv(cm.make_cfg(2, 8, 32, 32)).tune_placement() is None  # (small batches: nothing to alias)
     a.reset(init)
     b.reset(init)
