@@ -640,8 +640,11 @@ extern "C" int antsrl_step_update(AntsHandle *h, const int8_t *rotation, const i
     h->ev_armed = false;
     if (timed) (void)hipEventRecord(h->ev[0], st);
     // The sweep only reads phero[cur] and the wall bitmap, so it can be enqueued first: the
-    // perception gather of the step reads the same (pre-update) buffer.
-    if (!h->p.scaled) {
+    // perception gather of the step reads the same (pre-update) buffer.  Except behind a DEFERRED update: its deposits land
+    // in phero[cur] — this sweep's input — with k_update_move, so the sweep follows the step's kernels (the perception
+    // reads phero[cur], too, and nothing of the step reads the sweep's output).
+    const bool sweep_late = !h->p.scaled && h->pend_update;
+    if (!h->p.scaled && !sweep_late) {
         hipError_t e = antsrl_launch_sweep(h->p, h->cur, st);
         if (e != hipSuccess) return hip_fail(e, "pheromone sweep");
     }
@@ -663,6 +666,10 @@ extern "C" int antsrl_step_update(AntsHandle *h, const int8_t *rotation, const i
     int rc = do_step(h, rotation, phero, obs, agent_state, reward, done, st, fuse, wall_jitter, timed);
     if (rc) return rc;
     if (timed) (void)hipEventRecord(h->ev[3], st);
+    if (sweep_late) {
+        hipError_t e = antsrl_launch_sweep(h->p, h->cur, st);
+        if (e != hipSuccess) return hip_fail(e, "pheromone sweep");
+    }
     const bool was_done = h->host_timestep == h->cfg.max_time; // RL_api.py:200, same for every env
     const bool regen = was_done && h->has_gen && h->gen.auto_reset;
     rc = do_update(h, wall_jitter, st, true, fuse, !regen);

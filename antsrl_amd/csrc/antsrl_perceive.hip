@@ -939,7 +939,9 @@ hipError_t antsrl_launch_move(const KP &p, const int8_t *rot, const int8_t *ph, 
 // The deferred update of the previous step + this step's move in one launch (see k_update_move).
 bool antsrl_update_move_supported(const KP &p)
 {
-    return p.meta && p.scaled && p.C == 2 && p.N <= 1024 && !PROF_ENV("ANTSRL_NO_DEFER_UPDATE");
+    // (scaled units or an explicit sweep alike: with a sweep the host enqueues k_update_move AHEAD of the step's sweep, whose
+    //  input buffer the deferred deposit lands in — antsrl_step_update in antsrl_capi.hip)
+    return p.meta && p.C == 2 && p.N <= 1024 && !PROF_ENV("ANTSRL_NO_DEFER_UPDATE");
 }
 
 hipError_t antsrl_launch_update_move(const KP &p, int out_buf, double g_dep, double inv_g_dep, const int8_t *rot,

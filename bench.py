@@ -410,7 +410,9 @@ def main():
             if meta_path and deferred:
                 # antsrl_update is deferred into the next step: [1]..[2] brackets k_update_move (the previous step's
                 # update + this step's move), [3]..[4] is empty (include/antsrl.h)
-                kern = dict(sweep=float(ms[:, 0].mean()), update_move=float(ms[:, 1].mean()), perceive=float(ms[:, 2].mean()))
+                # (under an explicit sweep the step's sweep follows its kernels: [3]..[4], include/antsrl.h)
+                kern = dict(sweep=float(ms[:, 0].mean() if scaled else ms[:, 3].mean()), update_move=float(ms[:, 1].mean()),
+                            perceive=float(ms[:, 2].mean()))
                 ab["update_move"] = ab["move"] + ab["update"]
             elif meta_path:
                 kern = dict(sweep=float(ms[:, 0].mean()), move=float(ms[:, 1].mean()), perceive=float(ms[:, 2].mean()),
@@ -511,7 +513,8 @@ def main():
             env_x.step_update(rot[t % RING], ph[t % RING], None)
         torch.cuda.synchronize(dev)
         ms_x = (time.perf_counter() - t1) / KX * 1e3
-        sweep_ms = float(np.mean([evx.elapsed_ms(NEV * j, NEV * j + 1) for j in range(KX // EVX)]))
+        # ([0]..[1], or — behind a deferred update — [3]..[4]: the other bracket is empty, include/antsrl.h)
+        sweep_ms = float(np.mean([evx.elapsed_ms(NEV * j, NEV * j + 1) + evx.elapsed_ms(NEV * j + 3, NEV * j + 4) for j in range(KX // EVX)]))
         evx.destroy()
         out["explicit_sweep"] = dict(ms_per_step=round(ms_x, 4), k_sweep0_ms=round(sweep_ms, 4),
                                      k_sweep0_algorithmic_gbs=round(ab["sweep"] * E / (sweep_ms * 1e-3) / 1e9, 1),

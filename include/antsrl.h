@@ -308,8 +308,9 @@ int antsrl_observe(AntsHandle *h, float *obs, float *agent_state, float *reward,
  *   value np.random.random(k) would have returned in Walls.update (walls.py:28):
  *   the k-th colliding ant, in ant-index order, consumes it.  NULL = built-in
  *   counter-based generator keyed on (AntsCfg.rng_seed, AntsCfg.env_id_base + e, timestep, ant).
- * DEFERRED UPDATE.  With wall_jitter == NULL on the cell-meta path (scaled pheromone units, <= 1024 ants,
- * ANTSRL_Q_DEFERRED_UPDATE) the call does the update's bookkeeping and returns without enqueuing its kernel: the
+ * DEFERRED UPDATE.  With wall_jitter == NULL on the cell-meta path (<= 1024 ants, ANTSRL_Q_DEFERRED_UPDATE; scaled
+ * pheromone units or an explicit sweep alike) the call does the update's bookkeeping (and enqueues the pheromone sweep, if
+ * there is one) and returns without enqueuing the update's kernel: the
  * next antsrl_step / antsrl_step_update runs it in the same launch as its move (k_update_move: the move re-reads
  * what the update has just written — one launch and most of the second kernel's HBM fetches saved).  Every other
  * entry point that reads or replaces the state (antsrl_observe, antsrl_read_state, antsrl_set_activation, a second
@@ -338,7 +339,8 @@ int antsrl_step_update(AntsHandle *h, const int8_t *rotation, const int8_t *pher
  * [1] after it, [2] after the per-ant action kernel (k_move; equal to [1] where one kernel does both),
  * [3] after the perception kernel (k_perceive / k_act), [4] after the update kernel; the hook then
  * clears itself.  With a deferred update (antsrl_update) [1]..[2] brackets k_update_move — the PREVIOUS step's
- * update and this step's move — and [3]..[4] is empty. */
+ * update and this step's move — and [3]..[4] is empty under scaled units; under an explicit sweep the step's sweep
+ * follows its kernels then ([0]..[1] empty, [3]..[4] brackets the sweep: the deferred deposits land in its input). */
 #define ANTSRL_TIMING_EVENTS 5
 int antsrl_set_timing_events(AntsHandle *h, void *const *events);
 

@@ -415,7 +415,8 @@ def test_stencil_shapes_vs_oracle(torch_mod, radius, separable, W, H):
 
 @pytest.mark.parametrize("E,N,W,H,rocks", [(6, 512, 256, 256, 8), (3, 100, 64, 48, 2), (2, 1024, 128, 128, 0), (5, 37, 40, 40, 3),
                                            (16, 64, 48, 48, 2), (32, 100, 40, 56, 0)])  # (multiples of 16 envs: split-batch candidates)
-def test_deferred_update_is_bit_identical(torch_mod, E, N, W, H, rocks):
+@pytest.mark.parametrize("explicit", [None, "sweep0", "3x3", "radius3"], ids=["scaled", "explicit_sweep", "diffuse3x3", "radius3"])
+def test_deferred_update_is_bit_identical(torch_mod, E, N, W, H, rocks, explicit):
     """antsrl_update with the library's own wall jitter is deferred into the next step (k_update_move, include/antsrl.h
     "DEFERRED UPDATE").  Handle A runs the loop the way bench.py and main.py do (the update kernel always rides with
     the next move); handle B reads a state array after every update, which enqueues the deferred update at once
@@ -426,7 +427,18 @@ def test_deferred_update_is_bit_identical(torch_mod, E, N, W, H, rocks):
     from antsrl_amd.batched import BatchedAntsEnv
     from antsrl_amd.synth import random_actions, synth_init
     from oracle.oracle import Oracle
-    cfg = cm.make_cfg(E, N, W, H, n_rocks=rocks, deposit_strength=256.0, reward_kind=cm.REWARD_ALL, act_path=cm.ACT_CELL_META)
+    kw = {}
+    if explicit is not None:  # round 4: the update is deferred under an explicit sweep, too (the step's sweep then follows its kernels)
+        if W * H > 16384 and explicit != "sweep0":
+            pytest.skip("the oracle's float64 stencil over a 256 x 256 grid: covered at the smaller shapes")
+        kw["phero_mode"] = cm.PHERO_EXPLICIT_SWEEP
+        if explicit == "3x3":
+            kw["filt"] = cm.diffuse_filter(0.02, 0.001)
+        elif explicit == "radius3":
+            ax = np.arange(-3, 4)
+            g = np.exp(-(ax[:, None] ** 2 + ax[None, :] ** 2) / 4.5)
+            kw["filt"] = g / g.sum() * 0.999
+    cfg = cm.make_cfg(E, N, W, H, n_rocks=rocks, deposit_strength=256.0, reward_kind=cm.REWARD_ALL, act_path=cm.ACT_CELL_META, **kw)
     init = synth_init(cfg, seed=31 + N, wall_density=0.08)
     a, b = BatchedAntsEnv(cfg), BatchedAntsEnv(cfg)
     if a.query(cm.Q_DEFERRED_UPDATE) != 1:
