@@ -232,6 +232,14 @@ static void fill_kp(const AntsCfg *c, KP *p)
         p->ch_kind[k] = c->channel_kind[k];
         p->ch_arg[k] = c->channel_arg[k];
     }
+    p->mand_first = p->mand_last = 0;
+    for (int k = 0; k < c->n_channels; ++k) {
+        const int op = c->channel_kind[k] == ANTSRL_CH_FOOD ? 1 : c->channel_kind[k] == ANTSRL_CH_ANTHILL ? 2 : 0;
+        if (op && op != p->mand_last) {
+            p->mand_first = p->mand_last;
+            p->mand_last = op;
+        }
+    }
     memcpy(p->mask, c->mask, ANTSRL_MAX_PCELLS);
     p->delta = c->delta; p->fwd_delta = c->fwd_delta; p->max_speed = c->max_speed;
     p->max_rot_speed = c->max_rot_speed; p->carry = c->carry_speed_reduction;

@@ -57,8 +57,29 @@
 #ifndef UM_ABL
 #define UM_ABL 0
 #endif
-#if !defined(ANTSRL_PROFILING) && (PRC_ABL != 0 || UM_ABL != 0 || defined(PRC_TRACE))
-#error "PRC_ABL / UM_ABL / PRC_TRACE are profiling switches: build them with -DANTSRL_PROFILING (python -m antsrl_amd.build --variant NAME -D...)"
+#if !defined(ANTSRL_PROFILING) && (PRC_ABL != 0 || UM_ABL != 0 || defined(PRC_TRACE) || defined(UM_TRACE))
+#error "PRC_ABL / UM_ABL / PRC_TRACE / UM_TRACE are profiling switches: build them with -DANTSRL_PROFILING (python -m antsrl_amd.build --variant NAME -D...)"
+#endif
+
+// -DUM_TRACE (variant build; profiles/um_trace.py): the time line of every workgroup of k_update_move's last launch — its
+// thread 0 writes s_memrealtime (10 ns ticks) into g_um_trace[block][slot] at the phase boundaries.
+#ifdef UM_TRACE
+#define UM_TRACE_SLOTS 16
+#define UM_TRACE_MAX_WGS 4096
+static __device__ uint32_t g_um_trace[UM_TRACE_SLOTS * UM_TRACE_MAX_WGS]; // (one copy per translation unit; antsrl_perceive.hip's is the one read back)
+#define UM_STAMP(slot)                                                                                             \
+    do {                                                                                                           \
+        if (threadIdx.x == 0 && blockIdx.x < UM_TRACE_MAX_WGS) g_um_trace[blockIdx.x * UM_TRACE_SLOTS + (slot)] = (uint32_t)wall_clock64(); \
+    } while (0)
+// (the stamp waits until `v` — a value that depends on the loads of interest — is in a register)
+#define UM_STAMP_ON(slot, v)                                                                                       \
+    do {                                                                                                           \
+        asm volatile("" ::"v"(v));                                                                                 \
+        UM_STAMP(slot);                                                                                            \
+    } while (0)
+#else
+#define UM_STAMP(slot) do { } while (0)
+#define UM_STAMP_ON(slot, v) do { } while (0)
 #endif
 
 struct __align__(16) AntFrame { double cx, cy, ct, st; }; // perception centre, cos/sin(theta + pi/2)
@@ -66,12 +87,21 @@ struct __align__(16) AntFrame { double cx, cy, ct, st; }; // perception centre, 
 // and theta; the food value and META word of the cell the ant stands on (the deposit cell's record IS the record of the
 // move's mandible decision: one 16-byte load instead of a pheromone read, a dependent food read and an area-bit read);
 // and the move's own per-ant inputs, fetched in front of the update so that their round trip rides with the update's.
+// Round 4 (profiles/r04/um_trace.txt: the workgroup's life is a chain of exposed latencies, not bytes): the move's rotation and
+// its float64 sincos — ~400 VALU instructions that need theta and the action only — are evaluated by the UPDATE while its
+// record load is in flight (`pre`); the env's timestep and reward_primed flag travel along, so that thread 0 of the move
+// has no memory round trip of its own in front of the move's first barrier.
 struct UmFwd {
     double x, y, th;
+    double th_new, sn, cs; // pre: theta after the rotation, its sine and cosine (RL_api.py:190-196)
     float food, hold;
     uint32_t meta;
     int m, rot, pa;
-    int rec; // 1: food / meta are valid (interleaved records)
+    int rec;      // 1: food / meta are valid (interleaved records)
+    int pre;      // 1: th_new / sn / cs are valid
+    int has_rot;  // the step rotates (a rotation tensor was passed)
+    int ts;       // the env's timestep after the update
+    uint8_t primed; // reward_primed[e] as it stood at the launch
 };
 
 struct DState {
@@ -129,6 +159,10 @@ struct KP {
     int32_t HT;          // last-writer-wins hash table size (pow2 >= 2N)
     int32_t has_mask, has_max_val, reward_kind, max_time, filter_radius, explore_on;
     int32_t ch_kind[ANTSRL_MAX_CHANNELS], ch_arg[ANTSRL_MAX_CHANNELS];
+    // The mandible walk over perceived_objects (RL_api.py:178-185) reduced on the host: Food SETS the bit (q > 0), Anthill
+    // CLEARS it (on the area); both are idempotent, so the walk equals its last two distinct operations in order
+    // (S C S = C S, C S C = S C).  1 = set, 2 = clear, 0 = none: no per-channel scalar load in the ants' loop.
+    int32_t mand_first, mand_last;
     uint8_t mask[ANTSRL_MAX_PCELLS + 7];
     double delta, fwd_delta, max_speed, max_rot_speed, carry, backward, max_hold;
     double max_val, deposit_strength, threshold, reward_threshold;

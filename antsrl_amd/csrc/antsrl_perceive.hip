@@ -47,7 +47,7 @@ __device__ __forceinline__ void move_body(const KP &p, const int e, const int8_t
                                           const uint32_t seq, unsigned char *smem, const UmFwd *fw = nullptr)
 {
     const int tid = threadIdx.x, T = blockDim.x;
-    const int N = p.N, W = p.W, H = p.H, K = p.K;
+    const int N = p.N, W = p.W, H = p.H;
     const size_t G = (size_t)W * H, eN = (size_t)e * N;
     uint32_t *hkeys = (uint32_t *)smem, *hvals = hkeys + p.HT;
     float *tmp_q = (float *)(hvals + p.HT), *tmp_d = tmp_q + N;
@@ -61,7 +61,7 @@ __device__ __forceinline__ void move_body(const KP &p, const int e, const int8_t
 
     // One ant per thread (N <= T, the reference's sizes): every independent global load of the ant is issued
     // here, ahead of the first barrier; the phases below use the registers.
-    const bool one = N <= T; // wave-uniform
+    const bool one = fw ? true : N <= T; // wave-uniform (k_update_move: one ant per thread by construction, known at compile time)
     const size_t a1 = eN + (tid < N ? tid : 0);
     double h_x = 0.0, h_y = 0.0, h_th = 0.0;
     float h_hold = 0.0f, h_q = 0.0f;
@@ -98,15 +98,18 @@ __device__ __forceinline__ void move_body(const KP &p, const int e, const int8_t
             hvals[h] = 0u;
         }
     if (tid == 0) {
+        // (k_update_move: both values arrive in registers — no load, hence no memory round trip of thread 0's wave in
+        //  front of the barrier the whole workgroup waits at)
         if (p.reward_kind != ANTSRL_REWARD_NONE) {
             // the first observation after Reward.setup sees delta-holding == 0 (alias quirk,
             // reward_custom.py:35,68): k_perceive reads the flag as it stood before this observation
-            p.s.primed_cur[e] = p.s.reward_primed[e];
+            p.s.primed_cur[e] = fw ? fw->primed : p.s.reward_primed[e];
             p.s.reward_primed[e] = 1;
         }
-        if (do_step && done) done[e] = (uint8_t)(p.max_time == p.s.timestep[e]); // RL_api.py:200
+        if (do_step && done) done[e] = (uint8_t)(p.max_time == (fw ? fw->ts : p.s.timestep[e])); // RL_api.py:200
     }
     __syncthreads();
+    if (fw) UM_STAMP(10);
 
     if (do_step) {
         // ---- phase 1a: mandible target (RL_api.py:178-185) + Ants.update_mandibles reads
@@ -127,11 +130,14 @@ __device__ __forceinline__ void move_body(const KP &p, const int e, const int8_t
             }
             const uint32_t ccur = (uint32_t)((int)x * H + (int)y);
             int m = old_m;
-            for (int k = 0; k < K; ++k) { // perceived_objects order matters
-                if (p.ch_kind[k] == ANTSRL_CH_FOOD) m = (q > 0.0f) | m;                                // :182
-                else if (p.ch_kind[k] == ANTSRL_CH_ANTHILL)                                             // :184
-                    // (k_update_move: the ant still stands where the update left it — the forwarded record's own area bit)
-                    m = (1 - (int)((fw && fw->rec) ? (fw->meta & META_AREA) != 0 : test_bit(area, ccur))) & m;
+            { // perceived_objects order matters (:178-185): the walk's last two distinct operations, KP::mand_first / mand_last
+                const int set = q > 0.0f; // Food, :182
+                // Anthill, :184 (k_update_move: the ant still stands where the update left it — the forwarded record's own area bit)
+                const int keep = 1 - (int)((fw && fw->rec) ? (fw->meta & META_AREA) != 0 : test_bit(area, ccur));
+                if (p.mand_first == 1) m |= set;
+                else if (p.mand_first == 2) m &= keep;
+                if (p.mand_last == 1) m |= set;
+                else if (p.mand_last == 2) m &= keep;
             }
             const int closing = m & (1 - old_m), opening = (1 - m) & old_m; // ants.py:103-104
             const float taken = fminf((float)p.max_hold, fmaxf(0.0f, q)) * (float)closing; // :111
@@ -143,8 +149,10 @@ __device__ __forceinline__ void move_body(const KP &p, const int e, const int8_t
             tmp_q[i] = q;
             tmp_d[i] = dropped - taken;
             lww_insert(hkeys, hvals, (uint32_t)p.HT - 1, cprev, (uint32_t)i);
+            if (fw) break; // (one ant per thread: a single pass, known at compile time)
         }
         __syncthreads();
+        if (fw) UM_STAMP(11);
         // ---- phase 1b: ants.py:116 `qte[cell] += dropped - taken`, last ant on a cell wins
         for (int i = tid; i < N; i += T) {
             const uint32_t cprev = cprevs[i];
@@ -156,7 +164,9 @@ __device__ __forceinline__ void move_body(const KP &p, const int e, const int8_t
                 if (__float_as_uint((&food[cprev])[1]) & META_AREA) dirty = (int32_t)cprev;
             }
             STP_ST(p.s.dirty_cell[eN + i], dirty);
+            if (fw) break;
         }
+        if (fw) UM_STAMP(12);
     }
 
     // ---- phase 2: activation, rotate, move (RL_api.py:187-196), presence stamp
@@ -176,10 +186,14 @@ __device__ __forceinline__ void move_body(const KP &p, const int e, const int8_t
                 STP_ST(p.s.activation[(eN + i) * C + 0], a0);
                 if (C > 1) STP_ST(p.s.activation[(eN + i) * C + 1], a1);
             }
-            if (rotation) // Ants.rotate_ants + warp_theta, ants.py:62-67
-                th = np_mod_d(th + (double)(one ? h_rot : (int)rotation[eN + i]) * p.max_rot_speed, 2 * PI_D);
             double sn, cs;
-            sincos(th, &sn, &cs);
+            if (fw && fw->pre) { // (k_update_move: evaluated by the update under its record load — same operations, same inputs)
+                th = fw->th_new; sn = fw->sn; cs = fw->cs;
+            } else {
+                if (rotation) // Ants.rotate_ants + warp_theta, ants.py:62-67
+                    th = np_mod_d(th + (double)(one ? h_rot : (int)rotation[eN + i]) * p.max_rot_speed, 2 * PI_D);
+                sincos(th, &sn, &cs);
+            }
             // RL_api.py:194-196, Ants.forward_ants ants.py:77-80
             double fwd = 1.0 * p.max_speed * (1 - (double)(one ? h_hold : p.s.holding[eN + i]) * p.carry);
             if (fwd < 0) fwd *= p.backward;
@@ -194,7 +208,9 @@ __device__ __forceinline__ void move_body(const KP &p, const int e, const int8_t
         // (a plain store: as an nt store k_update_move gains 1 us and k_perceive, whose gathers then miss the line, loses 4:
         //  profiles/r03/ntstamp_ab.txt)
         if (!(UM_ABL & 2) || cell == 0xFFFFFFFFu) pres[(size_t)cell * FS2] = (uint16_t)seq;
+        if (fw) break;
     }
+    if (fw) UM_STAMP(13);
 }
 
 template <int C>
@@ -212,13 +228,17 @@ k_move(const KP p, const int8_t *__restrict__ rotation, const int8_t *__restrict
 // cell IS the food cell of the next mandible decision).  Back to back in one workgroup those reads are L1 / L2 hits
 // instead of HBM fetches, and one launch ramp and tail go away.  Same device functions as k_update_one / k_move:
 // the results are bit-identical to the two launches (tests/test_gpu_parity.py::test_deferred_update_is_bit_identical).
-template <int C>
-__global__ void __launch_bounds__(1024)
+// (1024, 8): at most 64 VGPRs (the kernel needs 66 without the bound and fits without a spill) — 8 waves per SIMD, i.e. FOUR
+// 512-thread workgroups per CU: c3's 1024 environments are resident at once instead of 768 + a 256-workgroup second round
+// (profiles/r04/um_trace*.txt); c4's 1024-thread workgroups two per CU instead of one.
+template <int C, bool ILV>
+__global__ void __launch_bounds__(1024, 8)
 k_update_move(const KP p, const int out_buf, const double g_dep, const double inv_g_dep, const int8_t *__restrict__ rotation,
               const int8_t *__restrict__ phero_act, uint8_t *__restrict__ done, const uint32_t seq)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const int e = env_of_block(blockIdx.x, p.E, seq);
+    UM_STAMP(0);
     UmFwd fw = {};
     { // the move's own per-ant inputs, ahead of the update: their memory round trip rides with the update's loads
         const size_t a = (size_t)e * p.N + (threadIdx.x < (unsigned)p.N ? threadIdx.x : 0);
@@ -226,10 +246,19 @@ k_update_move(const KP p, const int out_buf, const double g_dep, const double in
         fw.m = STP_LD(p.s.mandibles[a]);
         if (rotation) fw.rot = STP_LD(rotation[a]);
         if (phero_act) fw.pa = STP_LD(phero_act[a]);
+        fw.has_rot = rotation != nullptr;
+        fw.primed = p.s.reward_primed[e]; // (every thread, one address: a branch around a load would carry its own wait)
     }
-    update_one_body<C>(p, e, nullptr, out_buf, smem, g_dep, inv_g_dep, &fw);
+    fw.rec = (ILV && C == 2 && !(UM_ABL & 4)) ? 1 : 0; // (interleaved records: the update forwards the cell's food / META words)
+    update_one_body<C, ILV>(p, e, nullptr, out_buf, smem, g_dep, inv_g_dep, &fw);
     __syncthreads(); // the update's global writes are visible to the whole workgroup; its LDS is dead
+    UM_STAMP(9);
     move_body<C>(p, e, rotation, phero_act, done, 1, seq, smem, &fw);
+#ifdef UM_TRACE
+    __builtin_amdgcn_s_waitcnt(0x0F70); // (the trace build waits for the stores' acknowledgement: slot 14 - slot 13)
+    UM_STAMP(14);
+    if (threadIdx.x == 0 && blockIdx.x < UM_TRACE_MAX_WGS) g_um_trace[blockIdx.x * UM_TRACE_SLOTS + 15] = __builtin_amdgcn_s_getreg(4 | (31 << 11)); // HW_ID
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -355,6 +384,15 @@ __device__ __forceinline__ void policy_tile(const PolArgs &pol, const uint16_t *
 // 10 ns ticks (s_memrealtime): 0 entry, 1 past the prologue's barrier, 2 first gathers back (in front of the first group's work),
 // 3..6 behind group 1..4 of the first chunk (stores issued), 7 loop done, 8 in front of s_endpgm; 9 = HW_ID, 10 = XCC_ID.  The
 // stamps are kept in LDS (the launch needs ANTSRL_PRC_LDS_PAD >= 1) and written out by the wave's last instructions.
+#ifdef UM_TRACE
+extern "C" int antsrl_debug_read_um_trace(uint32_t *dst, int n_wgs)
+{
+    if (!dst || n_wgs < 0 || n_wgs > UM_TRACE_MAX_WGS) return ANTSRL_E_INVALID;
+    if (hipDeviceSynchronize() != hipSuccess) return ANTSRL_E_DEVICE;
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_um_trace), sizeof(uint32_t) * UM_TRACE_SLOTS * (size_t)n_wgs) == hipSuccess
+               ? ANTSRL_OK : ANTSRL_E_DEVICE;
+}
+#endif
 #ifdef PRC_TRACE
 #define PRC_TRACE_SLOTS 12
 #define PRC_TRACE_MAX_WAVES (1 << 17)
@@ -953,12 +991,16 @@ hipError_t antsrl_launch_update_move(const KP &p, int out_buf, double g_dep, dou
     static size_t seen[ANTSRL_MAX_DEVICES] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= ANTSRL_MAX_DEVICES) return hipErrorInvalidDevice;
+    const bool ilv = p.ps == 4; // {p0, p1, food, META} records
     if (lds > 64 * 1024 && lds > seen[dev]) {
-        hipError_t err = hipFuncSetAttribute((const void *)k_update_move<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t err = hipFuncSetAttribute((const void *)k_update_move<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (err == hipSuccess)
+            err = hipFuncSetAttribute((const void *)k_update_move<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (err != hipSuccess) return err;
         seen[dev] = lds;
     }
-    hipLaunchKernelGGL((k_update_move<2>), dim3(p.E), dim3(T), lds, st, p, out_buf, g_dep, inv_g_dep, rot, ph, done, seq);
+    if (ilv) hipLaunchKernelGGL((k_update_move<2, true>), dim3(p.E), dim3(T), lds, st, p, out_buf, g_dep, inv_g_dep, rot, ph, done, seq);
+    else hipLaunchKernelGGL((k_update_move<2, false>), dim3(p.E), dim3(T), lds, st, p, out_buf, g_dep, inv_g_dep, rot, ph, done, seq);
     return hipGetLastError();
 }
 

@@ -21,7 +21,10 @@ __host__ __device__ inline size_t update_one_lds_bytes(int HT, int R, int nwaves
 // `g_dep` / `inv_g_dep`: KP::g_dep / inv_g_dep as they stood at the update's own call (a deferred update runs after the
 // host has advanced them for the next observation).
 // `e`: the environment of this workgroup (blockIdx.x, or counted from the other end: env_of_block in antsrl_util.h).
-template <int C>
+// FWD_REC (k_update_move on interleaved records, p.ps == 4): the deposit cell's whole 16-byte record is loaded at once and
+// its food / META words are handed to the move — a template parameter so that no run-time branch joins two load forms
+// (the join's register copies would wait for the load on the spot).
+template <int C, bool FWD_REC = false>
 __device__ __forceinline__ void update_one_body(const KP &p, const int e, const double *__restrict__ wall_jitter, const int out_buf,
                                                 unsigned char *smem, const double g_dep, const double inv_g_dep, UmFwd *fw = nullptr)
 {
@@ -75,6 +78,7 @@ __device__ __forceinline__ void update_one_body(const KP &p, const int e, const 
     //  words c3 gains 0.9 % — 16 MB less competing for the Infinity Cache — and the latency-bound small batches lose 1-2 %, the
     //  first touch of the record line moving to the head of the dependency chain: profiles/r03/um_metabits_ab.txt)
     const bool hit = on && test_bit(walls, (uint32_t)((int)x * H + (int)y));
+    UM_STAMP(1); // (issued; the wait sits in front of the first use below)
     double u = 0.0;
     if (wall_jitter) { // k-th colliding ant (index order) takes the k-th draw
         uint32_t tot;
@@ -92,6 +96,7 @@ __device__ __forceinline__ void update_one_body(const KP &p, const int e, const 
     // (k_update_move: exactly what the move would load back; the move of the same launch overwrites x / y / theta, so the
     //  update's own stores of them would be dead)
     if (fw) fw->th = hit ? theta0 + (u - 0.5) : theta0;
+    UM_STAMP_ON(2, (int)hit); // (the wall bits are back)
 
     // ---- CircleObstacles.update, circle_obstacles.py:35-58
     if (R > 0) {
@@ -100,6 +105,7 @@ __device__ __forceinline__ void update_one_body(const KP &p, const int e, const 
             sy[tid] = y;
         }
         __syncthreads();
+        UM_STAMP(3);
         // pass 1: centres -= sum_over_ants(push)/weight, ants summed in index order (colliding ones only:
         // the others contribute exact zeros)
         for (int q = wave; q < R; q += nwaves) {
@@ -134,6 +140,7 @@ __device__ __forceinline__ void update_one_body(const KP &p, const int e, const 
             }
         }
         __syncthreads();
+        UM_STAMP(4);
         if (tid < R) {
             p.s.rock_cx[(size_t)e * R + tid] = rk[2 * tid + 0];
             p.s.rock_cy[(size_t)e * R + tid] = rk[2 * tid + 1];
@@ -154,6 +161,7 @@ __device__ __forceinline__ void update_one_body(const KP &p, const int e, const 
         x = warp_coord(x + ax, (double)W);
         y = warp_coord(y + ay, (double)H);
         moved = true;
+        UM_STAMP(5);
     }
 
     // ---- Ants.update, ants.py:123-130: prev := cur; deposit (pheromone.py:36-41)
@@ -164,17 +172,27 @@ __device__ __forceinline__ void update_one_body(const KP &p, const int e, const 
     // them; no other ant writes this cell in this update except the wall-deposit clear, and a deposit on a
     // wall cell ignores the old value)
     float pold[C];
-    if (fw && p.ps == 4 && C == 2 && !(UM_ABL & 4)) {
+    constexpr bool fw_rec = FWD_REC && C == 2 && !(UM_ABL & 4);
+    if constexpr (fw_rec) {
         // interleaved records: the WHOLE record of the cell in one 16-byte load — the move's food value and area bit with it
         const stream_f4 rec = *reinterpret_cast<const stream_f4 *>(out + (size_t)cell * 4);
         pold[0] = rec.x;
         pold[C - 1] = rec.y;
         fw->food = rec.z;
         fw->meta = __float_as_uint(rec.w);
-        fw->rec = 1;
     } else {
 #pragma unroll
         for (int c = 0; c < C; ++c) pold[c] = (UM_ABL & 4) ? 0.0f : out[(size_t)cell * PS + c]; // (UM_ABL 4: ablation, antsrl_device.h)
+    }
+    if (fw) {
+        // The move's rotation and sincos (RL_api.py:190-196, ants.py:62-67), HERE: they need theta and the action only, and
+        // the record load above is in flight — ~400 float64 VALU instructions under a memory round trip instead of behind it.
+        double th = fw->th;
+        if (fw->has_rot) th = np_mod_d(th + (double)fw->rot * p.max_rot_speed, 2 * PI_D);
+        fw->th_new = th;
+        sincos(th, &fw->sn, &fw->cs);
+        fw->pre = 1;
+        fw->ts = ts;
     }
     if (on) {
         if (moved && !fw) {
@@ -191,6 +209,7 @@ __device__ __forceinline__ void update_one_body(const KP &p, const int e, const 
         STP_ST(p.s.reward_state[a], (uint8_t)((double)rstate * 0.9)); // :130
     }
     __syncthreads();
+    UM_STAMP(6);
     if (p.scaled) {
         // a deposit that landed on a WALL cell in the previous update is zeroed by this update's Walls
         // pass (walls.py:30), before this update's deposits
@@ -199,6 +218,12 @@ __device__ __forceinline__ void update_one_body(const KP &p, const int e, const 
             p.s.walldep_cell[a] = -1;
         }
         __syncthreads();
+        UM_STAMP(7);
+    }
+    if constexpr (fw_rec) {
+        // The record's first use is HERE (and its food / META words in the move): without this the compiler extracts the area
+        // bit right behind the load and waits for it there — the whole round trip in front of the hash inserts and two barriers.
+        asm volatile("" : "+v"(pold[0]), "+v"(pold[C - 1]), "+v"(fw->food), "+v"(fw->meta));
     }
     double gain = 0.0;
     if (on) {
@@ -238,6 +263,7 @@ __device__ __forceinline__ void update_one_body(const KP &p, const int e, const 
             p.s.dirty_cell[a] = -1;
         }
     }
+    UM_STAMP(8); // (deposit and collect stores issued)
     for (int o = 32; o > 0; o >>= 1) gain += __shfl_down(gain, o);
     if (lane == 0) red[wave] = gain;
     __syncthreads();
