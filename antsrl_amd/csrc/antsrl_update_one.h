@@ -5,11 +5,11 @@
 #include "antsrl_update_env.h"
 
 // LDS of k_update_one: hash [HT] keys + values, rock table [R][4] + new centres [R][2], reduction and
-// scan scratch per wave, ants' x / y [N].
+// scan scratch per wave, ants' x / y [N], collider flag per rock [R].
 __host__ __device__ inline size_t update_one_lds_bytes(int HT, int R, int nwaves, int N)
 {
     return align_up(8 * (size_t)HT, 16) + 48 * (size_t)(R > 0 ? R : 1) + 8 * (size_t)nwaves +
-           align_up(4 * (size_t)nwaves, 8) + 16 * (size_t)N + 16;
+           align_up(4 * (size_t)nwaves, 8) + 16 * (size_t)N + align_up(4 * (size_t)R, 16) + 16;
 }
 
 // k_update for N <= 1024: ONE ant per thread.  Same phases and the same arithmetic as update_env,
@@ -38,6 +38,7 @@ __device__ __forceinline__ void update_one_body(const KP &p, const int e, const 
     double *red = rk + 2 * (R > 0 ? R : 1);                           // [nwaves]
     uint32_t *wave_tot = (uint32_t *)(red + nwaves);                  // [nwaves]
     double *sx = (double *)((unsigned char *)wave_tot + align_up(4 * (size_t)nwaves, 8)), *sy = sx + N;
+    uint32_t *rk_hit = (uint32_t *)(sy + N);                          // [R] pass 1 found a collider of this rock
 
     const uint32_t *walls = p.s.walls_bits + (size_t)e * p.words;
     const FoodView food{p.s.food + (size_t)e * G * p.fs, p.fs};
@@ -112,6 +113,7 @@ __device__ __forceinline__ void update_one_body(const KP &p, const int e, const 
             const double cx = rock[4 * q + 0], cy = rock[4 * q + 1], rad = rock[4 * q + 2];
             const double rad2_hi = rad * rad * (1.0 + 1e-12) + 1e-300; // d2 above this: sqrt(d2) > rad for sure
             double sumx = 0.0, sumy = 0.0;
+            bool any = false;
             for (int base = 0; base < N; base += 64) {
                 const int i = base + lane;
                 double px = 0.0, py = 0.0;
@@ -127,6 +129,7 @@ __device__ __forceinline__ void update_one_body(const KP &p, const int e, const 
                     }
                 }
                 unsigned long long m = __ballot(col);
+                any |= m != 0;
                 while (m) {
                     const int l = __builtin_ctzll(m);
                     m &= m - 1;
@@ -137,6 +140,7 @@ __device__ __forceinline__ void update_one_body(const KP &p, const int e, const 
             if (lane == 0) {
                 rk[2 * q + 0] = cx - sumx / rock[4 * q + 3];
                 rk[2 * q + 1] = cy - sumy / rock[4 * q + 3];
+                rk_hit[q] = any ? 1u : 0u;
             }
         }
         __syncthreads();
@@ -148,6 +152,9 @@ __device__ __forceinline__ void update_one_body(const KP &p, const int e, const 
         // pass 2 (:53-58): ants pushed out of the UPDATED rocks, then warp_xy
         double ax = 0.0, ay = 0.0;
         for (int q = 0; q < R; ++q) {
+            // A rock no ant touched in pass 1 has not moved, and an ant is pushed in pass 2 exactly when it was a collider of
+            // pass 1 (same centre, same d <= radius test): every push of this rock would be an exact zero
+            if (!rk_hit[q]) continue;
             const double vx = rk[2 * q + 0] - x, vy = rk[2 * q + 1] - y;
             const double rad = rock[4 * q + 2];
             const double d2 = vx * vx + vy * vy;
@@ -238,7 +245,11 @@ __device__ __forceinline__ void update_one_body(const KP &p, const int e, const 
                     }
                 }
             } else { // scaled units, see update_env
-                const bool on_wall = test_bit(walls, cell_id);
+                // (k_update_move: the cell's own record is in registers — its META word carries the wall bit the perception reads,
+                //  antsrl_state.hip; the bit map would be one more dependent load inside this phase)
+                bool on_wall;
+                if constexpr (fw_rec) on_wall = (fw->meta & META_WALL) != 0;
+                else on_wall = test_bit(walls, cell_id);
                 bool wrote = false;
 #pragma unroll
                 for (int c = 0; c < C; ++c) {
