@@ -382,7 +382,8 @@ __device__ __forceinline__ void policy_tile(const PolArgs &pol, const uint16_t *
 
 // Variant build only (-DPRC_TRACE; profiles/prc_trace.py): the time line of every wave of k_perceive's last launch, in
 // 10 ns ticks (s_memrealtime): 0 entry, 1 past the prologue's barrier, 2 first gathers back (in front of the first group's work),
-// 3..6 behind group 1..4 of the first chunk (stores issued), 7 loop done, 8 in front of s_endpgm; 9 = HW_ID, 10 = XCC_ID.  The
+// 3..6 behind group 1..4 of the first chunk (stores issued), 7 loop done, 8 every store acknowledged; 9 = HW_ID, 10 = XCC_ID;
+// POLICY: 11 behind the barrier in front of the in-loop net, 12 (wave 0) the net's actions are out.  The
 // stamps are kept in LDS (the launch needs ANTSRL_PRC_LDS_PAD >= 1) and written out by the wave's last instructions.
 #ifdef UM_TRACE
 extern "C" int antsrl_debug_read_um_trace(uint32_t *dst, int n_wgs)
@@ -394,7 +395,7 @@ extern "C" int antsrl_debug_read_um_trace(uint32_t *dst, int n_wgs)
 }
 #endif
 #ifdef PRC_TRACE
-#define PRC_TRACE_SLOTS 12
+#define PRC_TRACE_SLOTS 16
 #define PRC_TRACE_MAX_WAVES (1 << 17)
 __device__ uint32_t g_prc_trace[PRC_TRACE_SLOTS * PRC_TRACE_MAX_WAVES];
 #define PRC_STAMP(slot)                                                                       \
@@ -878,18 +879,26 @@ k_perceive(const KP p, const float *__restrict__ cells, float *__restrict__ obs,
 #ifdef PRC_TRACE
     __builtin_amdgcn_s_waitcnt(0x0F70); // (the trace measures when the wave's stores are acknowledged, too: slot 8 - slot 7)
     PRC_STAMP(8);
+#endif
+    if constexpr (POLICY) {
+        __syncthreads(); // every wave's rows and agent_state inputs are in the image
+        PRC_STAMP(11);
+        const int t0 = seg * nwaves * run; // first ant of this workgroup's tile
+        if (wave == 0) {
+            policy_tile(pol, pol_img, (uint32_t)(tile0 - pol_img), pol_as, (int)row, min(nwaves * run, N - t0), eN + (size_t)t0, lane);
+#ifdef PRC_TRACE
+            __builtin_amdgcn_s_waitcnt(0x0F70); // (the actions are out)
+#endif
+            PRC_STAMP(12);
+        }
+    }
+#ifdef PRC_TRACE
     wave_lds_sync();
     {
         const uint32_t wv = (uint32_t)blockIdx.x * nwaves + (uint32_t)wave;
         if (wv < PRC_TRACE_MAX_WAVES && lane < PRC_TRACE_SLOTS) g_prc_trace[wv * PRC_TRACE_SLOTS + lane] = prc_tr[lane];
     }
 #endif
-    if constexpr (POLICY) {
-        __syncthreads(); // every wave's rows and agent_state inputs are in the image
-        const int t0 = seg * nwaves * run; // first ant of this workgroup's tile
-        if (wave == 0)
-            policy_tile(pol, pol_img, (uint32_t)(tile0 - pol_img), pol_as, (int)row, min(nwaves * run, N - t0), eN + (size_t)t0, lane);
-    }
 }
 
 // ---------------------------------------------------------------------------------------------------

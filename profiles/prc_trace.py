@@ -1,7 +1,8 @@
 """Time line of k_perceive's waves (variant build -DPRC_TRACE, antsrl_perceive.hip): where does a workgroup's life go?
    python3 profiles/prc_trace.py [c3|c2|c4|c5|c5a]   (c5a: c5 act-only)      (on a GPU box; builds nothing: needs antsrl_amd/lib/variants/trace.so)
 Stamps (10 ns ticks): 0 entry, 1 past the prologue's barrier, 2 first gathers back, 3..6 behind group 1..4 (stores issued),
-7 loop done, 8 every store acknowledged (the trace build waits for them; the product does not)."""
+7 loop done, 8 every store acknowledged (the trace build waits for them; the product does not); in-loop policy (c5 / c5a):
+11 behind the barrier in front of the net, 12 (wave 0 only) the net's actions are out."""
 import os, sys, ctypes as C
 R = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
 os.environ["ANTSRL_LIB"] = os.path.join(R, "antsrl_amd/lib/variants/%s.so" % os.environ.get("TRACE_VARIANT", "trace"))
@@ -34,7 +35,7 @@ for t in range(age):
     else: env.step_update(rot[t % 8], ph[t % 8], None)
 torch.cuda.synchronize()
 nw = E * ((N + 31) // 32) * 4
-buf = np.zeros((nw, 12), np.uint32)
+buf = np.zeros((nw, 16), np.uint32)
 lib = _lib.load()
 lib.antsrl_debug_read_prc_trace.argtypes = [C.POINTER(C.c_uint32), C.c_int]
 assert lib.antsrl_debug_read_prc_trace(buf.ctypes.data_as(C.POINTER(C.c_uint32)), nw) == 0
@@ -62,6 +63,17 @@ if wg is not None:
     print("  workgroups resident per CU (sum of lives / span / 256): %.2f" % (wl.sum() / span / 256))
     skew = wg[:, :, 7].max(1) - wg[:, :, 7].min(1)
     print("  spread of the four waves' loop exits inside a workgroup: mean %.2f us" % skew[m].mean())
+if mlp and wg is not None:  # the in-loop net: one wave per workgroup evaluates the tile's 32 rows behind a workgroup barrier
+    pt = (buf[ok, 11].astype(np.int64) - t0) / 100.0
+    pe = (buf[ok, 12].astype(np.int64) - t0) / 100.0
+    ptw, pew = pt.reshape(-1, 4), pe.reshape(-1, 4)
+    wait = ptw - wg[:, :, 8]          # every wave: stores acknowledged -> past the barrier (waiting for the slowest wave)
+    net = pew[:, 0] - ptw[:, 0]       # wave 0: the net
+    full = pew[:, 0] - wg[:, :, 0].min(1)
+    print("  %-46s mean %6.2f us  median %6.2f  p90 %6.2f" % ("in-loop net: wait at its barrier (all waves)", wait[m].mean(), np.median(wait[m]), np.percentile(wait[m], 90)))
+    print("  %-46s mean %6.2f us  median %6.2f  p90 %6.2f" % ("in-loop net: wave 0 alone (MFMA tile + argmax)", net[m].mean(), np.median(net[m]), np.percentile(net[m], 90)))
+    print("  %-46s mean %6.2f us  median %6.2f  p90 %6.2f" % ("workgroup: first entry -> actions out", full[m].mean(), np.median(full[m]), np.percentile(full[m], 90)))
+    print("  workgroups resident per CU incl. the net's tail (sum of full lives / span / 256): %.2f" % (full.sum() / max(span, pew[:, 0].max()) / 256))
 # how many waves are alive over time
 ev = np.concatenate([np.stack([us[:, 0], np.ones(len(us))], 1), np.stack([us[:, 7], -np.ones(len(us))], 1)])
 ev = ev[np.argsort(ev[:, 0])]
