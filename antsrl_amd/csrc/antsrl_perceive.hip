@@ -4,7 +4,7 @@
 //   k_move      one workgroup per environment, one ant per thread: mandible decision + food exchange
 //               (RL_api.py:178-185, ants.py:102-117, LDS last-writer-wins), activation (ants.py:89-96),
 //               rotate, forward move (RL_api.py:190-196) and the presence stamp of the ant's cell
-//               (RL_api.py:137-142).  Every environment's workgroup is resident at once.
+//               (RL_api.py:137-142).  (The steady loop runs it fused behind the previous step's update: k_update_move.)
 //   k_perceive  the perception gather (RL_api.py:109-153) + rewards (rewards/reward_custom.py) + agent_state
 //               (RL_api.py:160-162).  ONE WAVE PER RUN OF ANTS, no per-environment state in LDS and no
 //               barrier after the prologue: each perceived cell is ONE gather that returns pheromone,
@@ -223,10 +223,11 @@ k_move(const KP p, const int8_t *__restrict__ rotation, const int8_t *__restrict
 }
 
 // Environment.update of step t (deferred by the host, include/antsrl.h "deferred update") and the move of step t + 1
-// in ONE launch: both are one-workgroup-per-environment, one-ant-per-thread kernels bound by scattered line traffic,
-// and the second re-reads what the first has just written — the ant's state and the record of its cell (the deposit
-// cell IS the food cell of the next mandible decision).  Back to back in one workgroup those reads are L1 / L2 hits
-// instead of HBM fetches, and one launch ramp and tail go away.  Same device functions as k_update_one / k_move:
+// in ONE launch: both are one-workgroup-per-environment, one-ant-per-thread kernels, and the second re-reads what the
+// first has just written — the ant's state and the record of its cell (the deposit cell IS the food cell of the next
+// mandible decision).  Back to back in one workgroup those values travel in registers (UmFwd), and one launch ramp and
+// tail go away.  What the kernel's time is made of is a chain of exposed latencies, not bytes: profiles/um_trace.py,
+// DESIGN.md section 5.1.  Same device functions as k_update_one / k_move:
 // the results are bit-identical to the two launches (tests/test_gpu_parity.py::test_deferred_update_is_bit_identical).
 // (1024, 8): at most 64 VGPRs (the kernel needs 66 without the bound and fits without a spill) — 8 waves per SIMD, i.e. FOUR
 // 512-thread workgroups per CU: c3's 1024 environments are resident at once instead of 768 + a 256-workgroup second round
