@@ -40,7 +40,7 @@ hipError_t antsrl_launch_policy_pack(unsigned char *pack, const float *w1, const
 hipError_t antsrl_launch_meta_rebase(const KP &p, hipStream_t st);
 bool antsrl_update_move_supported(const KP &p);
 hipError_t antsrl_launch_update_move(const KP &p, int out_buf, double g_dep, double inv_g_dep, const int8_t *rot,
-                                     const int8_t *ph, uint8_t *done, uint32_t seq, hipStream_t st);
+                                     const int8_t *ph, uint8_t *done, uint32_t seq, hipStream_t st, bool with_frames);
 int antsrl_perceive_run(const KP &p);
 hipError_t antsrl_launch_copy16(void *dst, const void *src, size_t bytes, hipStream_t st);
 
@@ -201,6 +201,7 @@ static size_t carve(const AntsCfg *c, DState *s, unsigned char *base)
         d.big_old = (uint32_t *)take(4 * E * words);
     }
     d.primed_cur = kp.meta ? (uint8_t *)take(E) : nullptr;
+    d.frames = kp.meta ? (AntFrame *)take(sizeof(AntFrame) * E * N) : nullptr;
     d.anthill_xyr = (int32_t *)take(4 * E * 3);
     d.anthill_food = (double *)take(8 * E);
     d.rock_cx = (double *)take(8 * E * (R ? R : 1)); d.rock_cy = (double *)take(8 * E * (R ? R : 1));
@@ -502,9 +503,16 @@ static int meta_observe(AntsHandle *h, const int8_t *rot, const int8_t *ph, floa
         h->obs_seq = 0;
     }
     h->obs_seq++;
+    bool frames = false; // k_update_move leaves the ants' perception frames for the k_perceive right behind it
     if (h->pend_update && stepping) { // the previous step's update and this step's move in one launch
         h->pend_update = false;
-        e = antsrl_launch_update_move(h->p, h->pend_out_buf, h->pend_p.g_dep, h->pend_p.inv_g_dep, rot, ph, done, h->obs_seq, st);
+        // Frames from k_update_move pay where k_perceive is latency-bound — the in-loop policy's launches, whose rows are
+        // bfloat16 or stay in LDS: c5 -2.5 %, k_perceive -5 % — and cost 1-2 us of a second sincos where it is bound by its
+        // float32 store stream, which hides the prologue anyway (c3 / c2 / c4: +1 %; profiles/r04/frames_ab.txt).
+        // ANTSRL_FRAMES=0 / 1 (profiling library): never / always.
+        frames = h->pol.pack != nullptr;
+        if (const char *s = PROF_ENV("ANTSRL_FRAMES")) frames = atoi(s) != 0;
+        e = antsrl_launch_update_move(h->p, h->pend_out_buf, h->pend_p.g_dep, h->pend_p.inv_g_dep, rot, ph, done, h->obs_seq, st, frames);
         if (e != hipSuccess) return hip_fail(e, "update + move");
     } else {
         int rc = flush_pending(h, st);
@@ -514,7 +522,7 @@ static int meta_observe(AntsHandle *h, const int8_t *rot, const int8_t *ph, floa
     }
     if (timed) (void)hipEventRecord(h->ev[2], st);
     e = antsrl_launch_perceive(h->p, h->cur, obs, agent_state, reward,
-                               (stepping ? ACT_STEP : 0) | (obs ? ACT_HAS_OBS : 0) |
+                               (stepping ? ACT_STEP : 0) | (obs ? ACT_HAS_OBS : 0) | (frames ? ACT_FRAMES : 0) |
                                    ((obs || h->pol.pack) && h->obs_bf16 ? ACT_OBS_BF16 : 0), // (act-only: rows in LDS, bf16)
                                h->obs_seq, st, &h->pol, h->obs_pitch);
     if (e == hipErrorNotSupported)

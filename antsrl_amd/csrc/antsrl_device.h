@@ -102,6 +102,7 @@ struct UmFwd {
     int has_rot;  // the step rotates (a rotation tensor was passed)
     int ts;       // the env's timestep after the update
     uint8_t primed; // reward_primed[e] as it stood at the launch
+    uint32_t frm_off; // LDS byte offset of the [T][2] doubles where the update parks cos / sin(theta + pi/2) for the frame
 };
 
 struct DState {
@@ -134,6 +135,8 @@ struct DState {
                                              //        environment's Python stream by k_gen_mt)
     // cell-meta layout only (KP::meta)
     uint8_t *primed_cur;                     // [E]   reward_primed as the current observation must see it
+    AntFrame *frames;                        // [E*N] the perception frames of the ants as k_update_move left them (ACT_FRAMES):
+                                             //       valid for the k_perceive launch that follows it, and for nothing else
     unsigned char *pol_pack;                 // ANTSRL_POL_PACK_BYTES: the in-loop policy's weights as MFMA fragments (antsrl_policy.hip)
 };
 
@@ -202,6 +205,7 @@ struct KP {
 #define ACT_HAS_OBS 2     // obs pointer valid
 #define ACT_FUSED_UPDATE 4 // run Environment.update of the same step at the tail of the launch
 #define ACT_OBS_BF16 8     // `obs` is a bfloat16 tensor (antsrl_set_obs_format): same values, rounded to nearest even
+#define ACT_FRAMES 16      // k_perceive: DState::frames holds this observation's frames (written by the k_update_move in front of it)
 // profiling ablations (env ANTSRL_ABLATE, results are WRONG with any of them set; bench/tests never set it)
 #define ACT_ABL_NO_ITEMS 256   // skip the perception phase
 #define ACT_ABL_NO_GATHER 512  // no pheromone/food gathers

@@ -208,6 +208,18 @@ __device__ __forceinline__ void move_body(const KP &p, const int e, const int8_t
         // (a plain store: as an nt store k_update_move gains 1 us and k_perceive, whose gathers then miss the line, loses 4:
         //  profiles/r03/ntstamp_ab.txt)
         if (!(UM_ABL & 2) || cell == 0xFFFFFFFFu) pres[(size_t)cell * FS2] = (uint16_t)seq;
+        if (fw && fw->frm_off) {
+            // the ant's perception frame, exactly as k_perceive's prologue builds it from the x / y / theta just stored
+            // (centre shifted by fwd_delta along the heading, RL_api.py:100-108): that launch then only loads it (ACT_FRAMES)
+            const double *fs = reinterpret_cast<const double *>(smem + fw->frm_off) + 2 * i;
+            AntFrame f;
+            const bool shifted = p.fwd_delta != 0.0;
+            f.cx = shifted ? x + fw->cs * p.fwd_delta : x;
+            f.cy = shifted ? y + fw->sn * p.fwd_delta : y;
+            f.ct = fs[0];
+            f.st = fs[1];
+            p.s.frames[eN + i] = f;
+        }
         if (fw) break;
     }
     if (fw) UM_STAMP(13);
@@ -235,7 +247,7 @@ k_move(const KP p, const int8_t *__restrict__ rotation, const int8_t *__restrict
 template <int C, bool ILV>
 __global__ void __launch_bounds__(1024, 8)
 k_update_move(const KP p, const int out_buf, const double g_dep, const double inv_g_dep, const int8_t *__restrict__ rotation,
-              const int8_t *__restrict__ phero_act, uint8_t *__restrict__ done, const uint32_t seq)
+              const int8_t *__restrict__ phero_act, uint8_t *__restrict__ done, const uint32_t seq, const int with_frames)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const int e = env_of_block(blockIdx.x, p.E, seq);
@@ -251,6 +263,8 @@ k_update_move(const KP p, const int out_buf, const double g_dep, const double in
         fw.primed = p.s.reward_primed[e]; // (every thread, one address: a branch around a load would carry its own wait)
     }
     fw.rec = (ILV && C == 2 && !(UM_ABL & 4)) ? 1 : 0; // (interleaved records: the update forwards the cell's food / META words)
+    // (with_frames: the host's choice per launch — antsrl_capi.hip, meta_observe; 0 = no frame is built, nothing is parked)
+    fw.frm_off = with_frames ? (uint32_t)align_up(max(update_one_lds_bytes(p.HT, p.R, (int)(blockDim.x >> 6), p.N), move_lds_bytes(p.HT, p.N)), 16) : 0u;
     update_one_body<C, ILV>(p, e, nullptr, out_buf, smem, g_dep, inv_g_dep, &fw);
     __syncthreads(); // the update's global writes are visible to the whole workgroup; its LDS is dead
     UM_STAMP(9);
@@ -518,6 +532,13 @@ k_perceive(const KP p, const float *__restrict__ cells, float *__restrict__ obs,
         const uint32_t wsel = (blockIdx.x >> 3) + (blockIdx.x >> 8);
         const int w_pro = (POLICY && nwaves > 1) ? 1 + (int)(wsel % (nwaves > 1 ? nwaves - 1 : 1)) : (int)(wsel % nwaves);
         const int w_rock = (w_pro + 1) % nwaves;
+        // ACT_FRAMES (the launch follows a k_update_move): the frames exist already — that kernel had the new position,
+        // the heading's sine and cosine and the action in registers and evaluated cos / sin(theta + pi/2) under its record
+        // load.  Every wave loads the frames of its own ants (32 bytes each): no sincos, no wave waiting for another one's,
+        // and without rocks no workgroup barrier at all in front of the first gathers.  Bit-identical by construction (the
+        // same expressions on the same stored x / y / theta): test_deferred_update_is_bit_identical compares the two forms.
+        const bool have_frames = (flags & ACT_FRAMES) != 0; // (launch-uniform)
+        if (have_frames && lane < n_run) frames[lane] = p.s.frames[eN + (size_t)PRC_ANT(lane)];
         if (wave == w_rock) {
             for (int q = lane; q < R; q += 64) {
                 const double rad = p.s.rock_r[(size_t)e * R + q];
@@ -527,7 +548,7 @@ k_perceive(const KP p, const float *__restrict__ cells, float *__restrict__ obs,
                 rock[4 * q + 3] = sqrt_lt_threshold(rad);
             }
         }
-        if (wave == w_pro) {
+        if (wave == w_pro && !have_frames) {
             const bool fwd = p.fwd_delta != 0.0;
             const int n_slot = nwaves * run, n_task = fwd ? 2 * n_slot : n_slot;
             for (int t = lane; t < n_task; t += 64) {
@@ -555,7 +576,8 @@ k_perceive(const KP p, const float *__restrict__ cells, float *__restrict__ obs,
                 }
             }
         }
-        __syncthreads(); // (the rock table and every wave's frames are complete)
+        if (!have_frames || R > 0) __syncthreads(); // (the rock table and every wave's frames are complete)
+        else wave_lds_sync();                       // (this wave's own frames)
         // the rocks whose disc can reach the patch (conservative; the exact test runs per cell below)
         if (lane < n_run) {
             uint32_t rm = 0u;
@@ -993,10 +1015,11 @@ bool antsrl_update_move_supported(const KP &p)
 }
 
 hipError_t antsrl_launch_update_move(const KP &p, int out_buf, double g_dep, double inv_g_dep, const int8_t *rot,
-                                     const int8_t *ph, uint8_t *done, uint32_t seq, hipStream_t st)
+                                     const int8_t *ph, uint8_t *done, uint32_t seq, hipStream_t st, bool with_frames)
 {
     const int T = (p.N + 63) / 64 * 64;
-    size_t lds = std::max(update_one_lds_bytes(p.HT, p.R, T / 64, p.N), move_lds_bytes(p.HT, p.N));
+    size_t lds = align_up(std::max(update_one_lds_bytes(p.HT, p.R, T / 64, p.N), move_lds_bytes(p.HT, p.N)), 16) +
+                 16 * (size_t)T; // + cos / sin(theta + pi/2) per ant, parked between the update and the move (UmFwd::frm_off)
     if (const char *s = PROF_ENV("ANTSRL_UM_LDS_PAD")) lds += (size_t)atoi(s) * 1024; // occupancy knob (profiling build)
     static size_t seen[ANTSRL_MAX_DEVICES] = {};
     int dev = 0;
@@ -1009,8 +1032,9 @@ hipError_t antsrl_launch_update_move(const KP &p, int out_buf, double g_dep, dou
         if (err != hipSuccess) return err;
         seen[dev] = lds;
     }
-    if (ilv) hipLaunchKernelGGL((k_update_move<2, true>), dim3(p.E), dim3(T), lds, st, p, out_buf, g_dep, inv_g_dep, rot, ph, done, seq);
-    else hipLaunchKernelGGL((k_update_move<2, false>), dim3(p.E), dim3(T), lds, st, p, out_buf, g_dep, inv_g_dep, rot, ph, done, seq);
+    const int wf = with_frames ? 1 : 0;
+    if (ilv) hipLaunchKernelGGL((k_update_move<2, true>), dim3(p.E), dim3(T), lds, st, p, out_buf, g_dep, inv_g_dep, rot, ph, done, seq, wf);
+    else hipLaunchKernelGGL((k_update_move<2, false>), dim3(p.E), dim3(T), lds, st, p, out_buf, g_dep, inv_g_dep, rot, ph, done, seq, wf);
     return hipGetLastError();
 }
 

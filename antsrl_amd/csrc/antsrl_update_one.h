@@ -200,6 +200,15 @@ __device__ __forceinline__ void update_one_body(const KP &p, const int e, const 
         sincos(th, &fw->sn, &fw->cs);
         fw->pre = 1;
         fw->ts = ts;
+        // ... and the rotation of the NEXT observation's frame, cos / sin(theta + pi/2) (RL_api.py:100-108; k_perceive's
+        // prologue would compute it behind a memory round trip of its own): parked in LDS until the move has the new position
+        if (fw->frm_off) {
+            double st2, ct2;
+            sincos(th + PI_D * 0.5, &st2, &ct2);
+            double *fs = reinterpret_cast<double *>(smem + fw->frm_off) + 2 * tid;
+            fs[0] = ct2;
+            fs[1] = st2;
+        }
     }
     if (on) {
         if (moved && !fw) {
