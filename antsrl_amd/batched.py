@@ -142,7 +142,7 @@ class BatchedAntsEnv:
         if pitch != row:
             _lib.check(self.lib.antsrl_set_obs_row_stride(self._h, pitch), "set_obs_row_stride")
 
-    def tune_placement(self, age: int = 150, steps: int = 30, verbose: bool = False, extra_outputs: int = 2):
+    def tune_placement(self, age: int = 150, steps: int = 30, verbose: bool = False, extra_outputs: int = 4):
         """Pick the (workspace, output buffer) pair whose PHYSICAL placement steps fastest.  Call it right after construction,
         BEFORE reset() / generate() and before anything is attached to the handle: it runs scratch episodes (device
         generator + uniform random actions), may re-create the handle on another workspace, and leaves it to be reset.
@@ -153,8 +153,8 @@ class BatchedAntsEnv:
         combinations {torch.empty, pieced} x {torch.empty, pieced} are each stepped `steps` times at the same point of the same
         scratch episode and the fastest pair is kept; the others are freed.  Then `extra_outputs` more output buffers of the
         default kind (fresh physical pieces) are tried on the torch workspace: on a device where that pair is the fast one, one
-        allocation in four or five still lands 4-5 % off (profiles/r04/box_id.txt), and another draw usually does not.
-        One-off cost ~0.3 s at c3.  Returns the ms/step figures, the four pairs first (None for small batches, where there is
+        allocation in four or five still lands 4-8 % off (profiles/r04/box_id.txt), and another draw usually does not.
+        One-off cost ~0.4 s at c3.  Returns the ms/step figures, the four pairs first (None for small batches, where there is
         nothing to alias)."""
         if self._out_total < vmm.SMALL_BYTES:
             return None

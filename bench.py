@@ -205,7 +205,7 @@ def main():
                     help="opt-in: observation rows a whole number of 128-byte lines apart (antsrl_set_obs_row_stride; measured 8 %% "
                          "SLOWER on c3: profiles/r04/obs_stride_ab_c3.txt) — the default and the headline are the dense tensor")
     ap.add_argument("--no-tune-placement", action="store_true",
-                    help="skip BatchedAntsEnv.tune_placement(): by default, before the episode is loaded, up to 6 candidate (workspace, output) "
+                    help="skip BatchedAntsEnv.tune_placement(): by default, before the episode is loaded, up to 8 candidate (workspace, output) "
                          "buffers are stepped on a scratch episode and the fastest physical placement is kept (~0.1 s, outside "
                          "every timed region; DESIGN.md section 2)")
     ap.add_argument("--no-obs", action="store_true",

@@ -92,7 +92,7 @@ def test_tune_placement_leaves_a_clean_handle():
     init = synth_init(cfg, seed=3)
     a, b = BatchedAntsEnv(cfg), BatchedAntsEnv(cfg)
     times = a.tune_placement(age=20, steps=8)
-    assert times is not None and len(times) == 6 and a.placement_trials["chosen"] in range(6)  # (four pairs + two more draws)
+    assert times is not None and len(times) == 8 and a.placement_trials["chosen"] in range(8)  # (four pairs + four more draws)
     assert len(BatchedAntsEnv(cfg).tune_placement(age=10, steps=4, extra_outputs=0)) == 4
     assert BatchedAntsEnv(cm.make_cfg(2, 8, 32, 32)).tune_placement() is None  # (small batches: nothing to alias)
     a.reset(init)
