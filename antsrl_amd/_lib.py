@@ -14,7 +14,8 @@ LIB_PATH = os.environ.get("ANTSRL_LIB") or os.path.join(os.path.dirname(os.path.
 EXPORTS = ("antsrl_abi_version", "antsrl_cfg_size", "antsrl_last_error", "antsrl_workspace_bytes", "antsrl_create",
            "antsrl_destroy", "antsrl_reset", "antsrl_generate", "antsrl_step", "antsrl_observe", "antsrl_update", "antsrl_flush",
            "antsrl_step_update", "antsrl_set_timing_events", "antsrl_set_activation", "antsrl_policy_mlp", "antsrl_read_state", "antsrl_state_bytes",
-           "antsrl_set_obs_format", "antsrl_query", "antsrl_bench_copy", "antsrl_set_inloop_policy", "antsrl_set_obs_row_stride", "antsrl_mem_alloc", "antsrl_mem_free")
+           "antsrl_set_obs_format", "antsrl_query", "antsrl_bench_copy", "antsrl_set_inloop_policy", "antsrl_set_obs_row_stride", "antsrl_mem_alloc", "antsrl_mem_free",
+           "antsrl_mem_trim", "antsrl_mem_stats")
 
 _lib = None
 
@@ -62,6 +63,8 @@ def load() -> C.CDLL:
     lib.antsrl_set_obs_row_stride.argtypes = [vp, i32]
     lib.antsrl_mem_alloc.argtypes = [C.c_size_t, i32, C.POINTER(vp)]
     lib.antsrl_mem_free.argtypes = [vp]
+    lib.antsrl_mem_trim.argtypes = []
+    lib.antsrl_mem_stats.argtypes = [C.POINTER(C.c_size_t)] * 4
     for name in EXPORTS:
         getattr(lib, name)  # AttributeError if the build lost a symbol
     lib.antsrl_cfg_size.restype = C.c_size_t

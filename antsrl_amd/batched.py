@@ -94,6 +94,7 @@ class BatchedAntsEnv:
             self.obs_row_pitch = pitch
             self._bind_outputs(big(total + 256).zero_())
         self._keep = None
+        self._loaded = None     # what has been done to the handle since construction (tune_placement refuses to run then)
         self._host_out = None   # pinned mirror of _out_flat (outputs_to_host)
         self._host_act = None   # pinned staging of numpy actions + the event of its last upload
         self._act_event = None
@@ -158,6 +159,10 @@ class BatchedAntsEnv:
         nothing to alias)."""
         if self._out_total < vmm.SMALL_BYTES:
             return None
+        if self._loaded:
+            # (it re-creates the handle: an episode, an activation matrix, an attached policy or timing events would be
+            #  dropped silently, and a scratch episode would be left in their place — ADVICE r4)
+            raise _lib.AntsrlError("tune_placement() must run right after construction: this handle has already been %s" % self._loaded)
         c = self.cfg
         E, N = c.n_envs, c.n_ants
         dev = self.device
@@ -223,6 +228,7 @@ class BatchedAntsEnv:
             self._out_flat.zero_()
             del own_ws, own_out, ws, out
         self.placement_trials = dict(ms_per_step=[round(t, 5) for t in times], chosen=best, pairs=labels)
+        self._loaded = None  # (the scratch episodes were the tuner's own: the handle is as new)
         return times
 
     @property
@@ -269,6 +275,7 @@ class BatchedAntsEnv:
                         for k in ("ants_xyt", "seed", "walls", "food", "anthill_xyr", "rocks", "phero")])
         with torch.cuda.device(self.device):
             _lib.check(self.lib.antsrl_reset(self._h, C.byref(ai), self._stream()), "reset")
+        self._loaded = "reset"
         self._keep = t  # inputs must outlive the enqueued reset kernels
 
     def generate(self, gen=None, episode_seed: int = 0, walls=None) -> None:
@@ -283,6 +290,7 @@ class BatchedAntsEnv:
             g.walls_input = self._gen_walls.data_ptr()  # kept alive: auto-reset reads it again
         with torch.cuda.device(self.device):
             _lib.check(self.lib.antsrl_generate(self._h, C.byref(g), int(episode_seed), self._stream()), "generate")
+        self._loaded = "given an episode (generate)"
 
     def _actions(self, rotation, phero):
         c = self.cfg
@@ -438,6 +446,7 @@ class BatchedAntsEnv:
         with torch.cuda.device(self.device):
             _lib.check(self.lib.antsrl_set_activation(self._h, _ptr(a), float(new_deposit_strength),
                                                       self._stream()), "set_activation")
+        self._loaded = "given an activation matrix"
 
     def read_state(self, which: int) -> torch.Tensor:
         c = self.cfg

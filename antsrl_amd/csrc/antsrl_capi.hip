@@ -385,7 +385,8 @@ extern "C" int antsrl_reset(AntsHandle *h, const AntsInit *init, void *stream)
 static int check_gen_seed(const AntsHandle *h, const AntsGen &g, uint64_t seed)
 {
     const uint64_t top = (uint64_t)h->p.env_id_base + (uint64_t)h->p.E; // < 2^31
-    if (g.rng_kind == ANTSRL_RNG_REFERENCE && (seed > 0xFFFFFFFFull / 5u || seed > 0xFFFFFFFFull / 5u - top))
+    const uint64_t lim = 0xFFFFFFFFull / 5u;                            // (top may exceed it: compare before subtracting)
+    if (g.rng_kind == ANTSRL_RNG_REFERENCE && (top > lim || seed > lim - top))
         return fail(ANTSRL_E_INVALID, "ANTSRL_RNG_REFERENCE: (episode_seed + env_id_base + n_envs) * 5 must stay below 2^32 (np.random.seed)");
     return ANTSRL_OK;
 }
@@ -469,6 +470,9 @@ extern "C" int antsrl_set_obs_row_stride(AntsHandle *h, int32_t stride_elems)
         return fail(ANTSRL_E_INVALID, "obs row stride %d: 0 (dense) or the row's %d elements rounded up to whole 128-byte lines (%d)",
                     stride_elems, row, (row * esz + 127) / 128 * 128 / esz);
     if (!h->p.meta) return fail(ANTSRL_E_UNSUPPORTED, "antsrl_set_obs_row_stride needs the cell-meta path (ANTSRL_Q_CELL_META)");
+    if (h->pol.pack) // (refused HERE, not in the middle of a step whose move has already been enqueued)
+        return fail(ANTSRL_E_UNSUPPORTED, "a padded observation row stride and the in-loop policy exclude each other (the net reads a "
+                                          "dense tile image): switch the policy off first (antsrl_set_inloop_policy with w1 == NULL)");
     h->obs_pitch = (uint32_t)stride_elems;
     return ANTSRL_OK;
 }
@@ -497,6 +501,8 @@ static int meta_observe(AntsHandle *h, const int8_t *rot, const int8_t *ph, floa
                         float *reward, uint8_t *done, bool stepping, hipStream_t st, bool timed)
 {
     hipError_t e;
+    if (obs && h->obs_pitch != 0 && h->obs_pitch != (uint32_t)(h->p.PP * h->p.K) && h->pol.pack && h->obs_bf16) // (both setters refuse the
+        return fail(ANTSRL_E_UNSUPPORTED, "a padded observation row stride and the in-loop policy exclude each other"); // pair; before any launch)
     if (h->obs_seq >= META_NEVER - 2) { // explored stamps: re-base long before the counter can reach "never"
         e = antsrl_launch_meta_rebase(h->p, st);
         if (e != hipSuccess) return hip_fail(e, "explored-stamp rebase");
@@ -792,6 +798,9 @@ extern "C" int antsrl_set_inloop_policy(AntsHandle *h, int32_t n_features, const
     if (!h->obs_bf16 || !antsrl_inloop_policy_supported(h->p))
         return fail(ANTSRL_E_UNSUPPORTED, "inloop_policy needs the cell-meta path (ANTSRL_Q_CELL_META) with bfloat16 "
                                           "observations (antsrl_set_obs_format) — use antsrl_policy_mlp otherwise");
+    if (h->obs_pitch != 0 && h->obs_pitch != (uint32_t)(h->p.PP * h->p.K))
+        return fail(ANTSRL_E_UNSUPPORTED, "the in-loop policy and a padded observation row stride exclude each other (the net reads a "
+                                          "dense tile image): antsrl_set_obs_row_stride(h, 0) first");
     hipError_t e = antsrl_launch_policy_pack(h->p.s.pol_pack, w1, b1, w2, b2, w3, b3, n_features, (hipStream_t)stream);
     if (e != hipSuccess) return hip_fail(e, "inloop_policy pack");
     h->pol.pack = h->p.s.pol_pack;

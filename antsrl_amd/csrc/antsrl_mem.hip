@@ -11,8 +11,19 @@
 // profiles/r03/box_state_probe3.txt).  Not a law: BOTH buffers pieced was slower again, and some processes' first
 // allocations stay slow either way, which is why the host side measures (BatchedAntsEnv.tune_placement,
 // profiles/r04/ROUND_NOTES.md).  Offsets INSIDE an allocation change nothing (placement_probe.txt).
+// Freed blocks are POOLED, not unmapped (round 5): antsrl_mem_free parks the block — range and pieces, still mapped — on a
+// per-device free list keyed by its size, antsrl_mem_alloc hands a parked block of the same device and size back before it
+// creates anything.  No hipMemUnmap on any path a running program takes, so no address is ever translated to anything but
+// the pieces it was first mapped to, and the reserved address space is bounded by the largest set of blocks that were live
+// (or parked) at once.  Why this matters: on ROCm 7.2 / gfx950 a range that was unmapped, freed and reserved again could
+// still be translated to its OLD physical pieces — two live buffers then aliased each other's memory, silently
+// (profiles/r04/vmm_stress.py: 95 of 300 allocate / fill / check / free rounds).  Round 4 retired every freed range for the
+// life of the process (no reuse, so no stale translation — and unbounded address-space growth: ADVICE r4); the pool needs
+// neither.  Physical memory goes back to the device in antsrl_mem_trim() only (explicit; ranges unmapped there ARE
+// retired), or with the process.
 // Host code only; no kernel here.
 #include <hip/hip_runtime.h>
+#include <map>
 #include <mutex>
 #include <unordered_map>
 #include <vector>
@@ -20,24 +31,38 @@
 
 namespace {
 struct Block {
-    size_t size, piece;
+    size_t size = 0, piece = 0;
+    int device = 0; // the device the pieces live on (and the one a free / trim synchronises)
     std::vector<hipMemGenericAllocationHandle_t> pieces;
 };
 std::mutex g_mu;
-std::unordered_map<void *, Block> g_blocks;
+std::unordered_map<void *, Block> g_live;                        // handed out
+std::multimap<std::pair<int, size_t>, std::pair<void *, Block>> g_pool; // parked, still mapped: (device, size) -> block
+size_t g_reserved = 0, g_retired = 0, g_pooled = 0;              // bytes of address space reserved / retired, bytes parked
 
-// The physical pieces go back to the device; the VIRTUAL range is never handed out again (`keep_va`: it stays reserved
-// for the life of the process).  On ROCm 7.2 / gfx950 a range that was unmapped, freed and reserved again can still be
-// translated to its OLD physical pieces by the GPU: two live buffers then alias each other's memory — silently
-// (profiles/r04/vmm_stress.py: 95 of 300 allocate / fill / check / free rounds, with one hipMemUnmap per range or one per
-// piece, with the device idle, with 100 ms of waiting).  A virtual address that is never reused cannot meet a stale
-// translation; address space is not a scarce resource (a c3 observation tensor is 0.7 GB of a 128 TB space).
-void release(void *base, Block &b, size_t mapped, bool keep_va)
+// Waits until nothing enqueued on the BLOCK's device can still touch it (the caller's current device may be another one).
+void sync_device(int device)
 {
+    int prev = -1;
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != device && hipSetDevice(device) != hipSuccess) return;
     (void)hipDeviceSynchronize();
+    if (prev >= 0 && prev != device) (void)hipSetDevice(prev);
+}
+
+// Physical pieces back to the device.  The range itself stays reserved and is never handed out again (retired): a range
+// that is never reused cannot meet a stale translation.  Only antsrl_mem_trim and a failed allocation come here.
+void unmap_and_retire(void *base, Block &b, size_t mapped)
+{
+    sync_device(b.device);
     for (size_t off = 0; off < mapped; off += b.piece) (void)hipMemUnmap((char *)base + off, b.piece);
     for (auto h : b.pieces) (void)hipMemRelease(h);
-    if (base && !keep_va) (void)hipMemAddressFree(base, b.size);
+    if (base && mapped == 0) {
+        (void)hipMemAddressFree(base, b.size); // (nothing was ever mapped there: no translation exists)
+        g_reserved -= b.size;
+    } else if (base) {
+        g_retired += b.size;
+    }
 }
 } // namespace
 
@@ -55,15 +80,27 @@ extern "C" int antsrl_mem_alloc(size_t bytes, int device, void **ptr)
     size_t gran = 0;
     int rc = ANTSRL_E_DEVICE;
     Block b{};
+    b.device = device;
     void *base = nullptr;
     size_t mapped = 0;
+    std::lock_guard<std::mutex> lk(g_mu);
     do {
         if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended) != hipSuccess || gran == 0) break;
         const size_t piece = (ANTSRL_MEM_PIECE_BYTES + gran - 1) / gran * gran;
         const size_t n = (bytes + piece - 1) / piece;
         b.size = n * piece;
         b.piece = piece;
+        auto it = g_pool.find({device, b.size});
+        if (it != g_pool.end()) { // a parked block of this device and size: the same range on the same pieces, nothing to map
+            base = it->second.first;
+            b = std::move(it->second.second);
+            g_pool.erase(it);
+            g_pooled -= b.size;
+            rc = ANTSRL_OK;
+            break;
+        }
         if (hipMemAddressReserve(&base, b.size, piece, nullptr, 0) != hipSuccess) { base = nullptr; break; }
+        g_reserved += b.size;
         bool ok = true;
         for (size_t i = 0; i < n && ok; ++i) {
             hipMemGenericAllocationHandle_t h;
@@ -80,10 +117,10 @@ extern "C" int antsrl_mem_alloc(size_t bytes, int device, void **ptr)
         rc = ANTSRL_OK;
     } while (false);
     if (rc != ANTSRL_OK) {
-        release(base, b, mapped, mapped != 0); // (a range that was mapped at all is retired, too)
+        if (base) unmap_and_retire(base, b, mapped);
+        else for (auto h : b.pieces) (void)hipMemRelease(h);
     } else {
-        std::lock_guard<std::mutex> lk(g_mu);
-        g_blocks.emplace(base, std::move(b));
+        g_live.emplace(base, std::move(b));
         *ptr = base;
     }
     (void)hipSetDevice(prev);
@@ -96,11 +133,38 @@ extern "C" int antsrl_mem_free(void *ptr)
     Block b;
     {
         std::lock_guard<std::mutex> lk(g_mu);
-        auto it = g_blocks.find(ptr);
-        if (it == g_blocks.end()) return ANTSRL_E_INVALID;
+        auto it = g_live.find(ptr);
+        if (it == g_live.end()) return ANTSRL_E_INVALID;
         b = std::move(it->second);
-        g_blocks.erase(it);
+        g_live.erase(it);
     }
-    release(ptr, b, b.size, true);
+    // Nothing enqueued may still touch the block when its next owner gets it (hipFree synchronises, too) — on the block's
+    // own device, whichever one is current.
+    sync_device(b.device);
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_pooled += b.size;
+    const std::pair<int, size_t> key{b.device, b.size};
+    g_pool.emplace(key, std::make_pair(ptr, std::move(b)));
+    return ANTSRL_OK;
+}
+
+extern "C" int antsrl_mem_trim(void)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (auto &kv : g_pool) unmap_and_retire(kv.second.first, kv.second.second, kv.second.second.size);
+    g_pool.clear();
+    g_pooled = 0;
+    return ANTSRL_OK;
+}
+
+extern "C" int antsrl_mem_stats(size_t *live_bytes, size_t *pooled_bytes, size_t *reserved_va_bytes, size_t *retired_va_bytes)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    size_t live = 0;
+    for (auto &kv : g_live) live += kv.second.size;
+    if (live_bytes) *live_bytes = live;
+    if (pooled_bytes) *pooled_bytes = g_pooled;
+    if (reserved_va_bytes) *reserved_va_bytes = g_reserved;
+    if (retired_va_bytes) *retired_va_bytes = g_retired;
     return ANTSRL_OK;
 }

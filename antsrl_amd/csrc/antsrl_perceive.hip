@@ -491,16 +491,33 @@ k_perceive(const KP p, const float *__restrict__ cells, float *__restrict__ obs,
     // {holding, seed} of the tile's ants
     uint16_t *pol_img = reinterpret_cast<uint16_t *>(smem + align_up(lo.total, 16));
     float *pol_as = reinterpret_cast<float *>(pol_img + prc_policy_img_elems(PP * K));
-    if constexpr (POLICY) {
-        for (uint32_t i = tid; i < prc_policy_img_elems(PP * K) / 8; i += PRC_TPB)
-            reinterpret_cast<uint4 *>(pol_img)[i] = make_uint4(0, 0, 0, 0); // rows of ants past the env's end stay zero
-    }
     // The image doubles as the copy-out staging of all four waves: it starts at the tile's own 16-byte misalignment in
     // the observation tensor, so LDS and global addresses of every row agree modulo 16 bytes (no per-wave staging rows:
     // a third less LDS per workgroup, one LDS write per value).
     const size_t tile_elem0 = ((size_t)e * N + (size_t)(seg * nwaves * run)) * (size_t)(PP * K);
     uint16_t *tile0 = pol_img + (uint32_t)((((uintptr_t)obs >> 1) + tile_elem0) & 7);
     (void)tile0;
+    if constexpr (POLICY) {
+        // What the net reads and no row store covers must be zero: the rows of tile slots past the environment's end, the
+        // alignment shift in front of row 0 and the pad the last k-step reads into.  Every wave zeroes the rows of ITS OWN
+        // empty slots (element-wide stores: a row's neighbours belong to other waves), wave 0 the shift and the pad — no
+        // wave ever stores into bytes another wave stages, so the zeroing needs no barrier in front of the staging (the
+        // barrier in front of policy_tile orders all of it).  Until round 4 the whole workgroup cleared the whole image
+        // here, thread t the pieces t + 256 k: behind ACT_FRAMES without rocks the prologue has no workgroup barrier, and a
+        // lagging wave's zeros could land on rows another wave had already staged.
+        const uint32_t rowe = (uint32_t)PP * (uint32_t)K, n_img = prc_policy_img_elems(PP * K);
+        const int t0_ = seg * nwaves * run;
+        for (int j = 0; j < run; ++j) {
+            if (t0_ + wave * run + j < N) continue; // (wave-uniform)
+            uint16_t *rz = tile0 + (uint32_t)(wave * run + j) * rowe;
+            for (uint32_t i = lane; i < rowe; i += 64) rz[i] = 0;
+        }
+        if (wave == 0) {
+            const uint32_t sh = (uint32_t)(tile0 - pol_img), tail0 = sh + (uint32_t)(nwaves * run) * rowe;
+            if ((uint32_t)lane < sh) pol_img[lane] = 0;
+            for (uint32_t i = tail0 + lane; i < n_img; i += 64) pol_img[i] = 0;
+        }
+    }
 
     const size_t eN = (size_t)e * N;
     const int t_begin = seg * nwaves * run; // first ant of the workgroup's tile

@@ -102,6 +102,7 @@ class LinearPolicy:
             _lib.check(self._lib.antsrl_set_inloop_policy(env._h, self.n_features, p(self.w1), p(self.b1), p(self.w2), p(self.b2),
                                                           p(self.w3), p(self.b3), p(env.next_rotation), p(env.next_pheromone), st),
                        "set_inloop_policy")
+        env._loaded = "given an in-loop policy"
 
     def detach(self, env) -> None:
         _lib.check(self._lib.antsrl_set_inloop_policy(env._h, self.n_features, None, None, None, None, None, None, None, None, None),

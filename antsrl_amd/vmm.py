@@ -25,7 +25,8 @@ class _Holder:
 
 
 class _Mapping:
-    """One antsrl_mem_alloc range; freed when the last tensor over it has gone."""
+    """One antsrl_mem_alloc range; handed back to the library's pool when the last tensor over it has gone (the pool keeps
+    it mapped and gives it to the next request of the same size: antsrl_mem.hip; `trim()` returns pooled memory to the device)."""
 
     def __init__(self, nbytes: int, dev: torch.device):
         self.lib = _lib.load()
@@ -39,8 +40,7 @@ class _Mapping:
     def __del__(self):
         p, self.ptr = getattr(self, "ptr", None), None
         if p and C is not None and torch is not None:  # (at interpreter shutdown the modules may be gone: the process's memory goes with it)
-            try:
-                torch.cuda.synchronize()  # nothing enqueued may still touch the range (hipFree synchronises, too)
+            try:  # (antsrl_mem_free waits for the BLOCK's device — nothing enqueued may still touch it — and parks it in the pool)
                 self.lib.antsrl_mem_free(C.c_void_p(p))
             except Exception:
                 pass
@@ -68,3 +68,8 @@ def empty_u8(nbytes: int, device) -> torch.Tensor:
         warnings.warn("antsrl_mem_alloc failed (%s): falling back to torch.empty — physically contiguous memory can cost the "
                       "observation kernel 15 %% on MI355X" % e)
         return torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+
+
+def trim() -> None:
+    """Returns every pooled (freed) block's physical memory to the device (antsrl_mem_trim)."""
+    _lib.check(_lib.load().antsrl_mem_trim(), "mem_trim")

@@ -103,6 +103,33 @@ class HipEvents:
             self.hip.hipEventDestroy(e)
 
 
+def device_identity(torch, index):
+    """What tells one MI355X from another across runs: the KFD unique id of the device (the figure `rocm-smi --showuniqueid`
+    prints; read from the topology, matched through the PCI address), else the uuid / PCI address torch reports."""
+    pci = None
+    try:
+        props = torch.cuda.get_device_properties(index)
+        pci = "%04x:%02x:%02x" % (getattr(props, "pci_domain_id", 0), props.pci_bus_id, props.pci_device_id)
+    except Exception:
+        props = None
+    try:
+        base = "/sys/class/kfd/kfd/topology/nodes"
+        for node in sorted(os.listdir(base)):
+            kv = dict(line.split(None, 1) for line in open(os.path.join(base, node, "properties")) if " " in line)
+            if int(kv.get("simd_count", "0")) == 0:
+                continue  # (a CPU node)
+            loc, dom = int(kv.get("location_id", "0")), int(kv.get("domain", "0"))
+            if pci is not None and "%04x:%02x:%02x" % (dom, (loc >> 8) & 0xFF, (loc >> 3) & 0x1F) != pci:
+                continue
+            uid = int(kv.get("unique_id", "0"))
+            if uid:
+                return "0x%016x" % uid
+    except Exception:
+        pass
+    u = getattr(props, "uuid", None) if props is not None else None
+    return str(u) if u is not None else ("pci " + pci if pci else None)
+
+
 def usable_cores():
     """CPU share this process may really use: affinity mask capped by the cgroup quota."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -226,6 +253,16 @@ def main():
     if args.gpus > 1 and world == 1:
         sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
+    # ANTSRL_BENCH_BACKEND=gloo + ANTSRL_BENCH_ONE_GPU=1: a one-GPU box's rehearsal of `torch.distributed.run --nproc-per-node N
+    # bench.py --gpus N` — every rank on device 0 (RCCL refuses two ranks on one device, so the transport is gloo); everything
+    # else is the code the driver's 8-GPU run executes: per-rank shards with their global env ids, tune_placement per rank, the
+    # per-step gather, the MAX over ranks, the per-rank arrays of the JSON line.  Not a scaling measurement.
+    backend = os.environ.get("ANTSRL_BENCH_BACKEND", "nccl")
+    one_gpu = os.environ.get("ANTSRL_BENCH_ONE_GPU") == "1"
+    if backend not in ("nccl", "gloo"):
+        sys.exit("ANTSRL_BENCH_BACKEND must be nccl (RCCL) or gloo")
+    if one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -244,7 +281,10 @@ def main():
             os.environ.setdefault("MASTER_PORT", "29533")
             os.environ.setdefault("RANK", "0")
             os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=dev)  # backend "nccl" is RCCL on ROCm
+        if backend == "gloo":
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)  # backend "nccl" is RCCL on ROCm
         if not force_dist:  # one rank per GPU, all of them in the process group
             assert dist.get_world_size() == args.gpus == world, \
                 "bench.py --gpus %d: the RCCL process group has %d ranks (WORLD_SIZE %d)" % (args.gpus, dist.get_world_size(), world)
@@ -369,7 +409,7 @@ def main():
     # REPEATS timed regions of exactly K steps each, every one bracketed by barrier + synchronize on both
     # sides and reduced with MAX over the ranks; `value` is the MEDIAN region (median of 5),
     # the spread is reported beside it.
-    region_s = []
+    region_s, region_local_s = [], []
     step_no = args.age + args.warmup
     for rep in range(REPEATS):
         barrier()
@@ -381,6 +421,7 @@ def main():
             step_no += 1
         gathered, t_done = barrier()
         el = t_done - t0
+        region_local_s.append(el)  # this rank's own clock, before the MAX over ranks
         if dist is not None:
             tmax = torch.tensor([el], dtype=torch.float64, device=dev)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -388,11 +429,39 @@ def main():
         region_s.append(el)
         check_gather(gathered)
     elapsed = float(np.median(region_s))
-    bases = [env_id_base]
-    if dist is not None:  # every rank's first global env id, for the line: the run documents its own sharding
-        tb = torch.zeros(dist.get_world_size(), dtype=torch.int64, device=dev)
-        dist.all_gather_into_tensor(tb, torch.tensor([env_id_base], dtype=torch.int64, device=dev))
-        bases = [int(v) for v in tb.tolist()]
+    # What the gather costs THIS rank per step: a region with it minus a gather-free region of the same rank, once, outside
+    # the timed regions (on an 8-GPU node a slow device and a slow collective must be told apart from the line alone).
+    gather_overhead_us = None
+    if gather is not None:
+        KG = max(10, min(K, 50))
+        plain = ShardedStepper(env, None, args.gather)
+
+        def local_region(stp):
+            stepper.drain()
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            for t in range(KG):
+                stp.step(step_no + t, lambda: device_step(step_no + t))
+            stp.drain()
+            torch.cuda.synchronize(dev)
+            return (time.perf_counter() - t1) / KG
+        local_region(stepper)  # (warm)
+        with_g = min(local_region(stepper) for _ in range(2))
+        without_g = min(local_region(plain) for _ in range(2))
+        gather_overhead_us = round((with_g - without_g) * 1e6, 2)
+        if args.gather == "zero_copy":  # (the plain stepper left reward / done on a send slot: harmless, the run is over)
+            pass
+    pt = getattr(env, "placement_trials", None) if placement else None
+    mine = dict(rank=rank, env_id_base=env_id_base, ms_per_step=float(np.median(region_local_s)) / K * 1e3,
+                device=device_identity(torch, local_rank), gather_overhead_us=gather_overhead_us,
+                placement_chosen_ms=(pt["ms_per_step"][pt["chosen"]] if pt else None),
+                placement_default_ms=(pt["ms_per_step"][0] if pt else None))
+    per_rank = [mine]
+    if dist is not None:  # every rank's own figures, for the line: the run documents its own sharding and its own devices
+        per_rank = [None] * dist.get_world_size()
+        dist.all_gather_object(per_rank, mine)
+        per_rank.sort(key=lambda r: r["rank"])
+    bases = [r["env_id_base"] for r in per_rank]
 
     out = None
     if rank == 0:
@@ -466,8 +535,16 @@ def main():
             "vs_baseline": None, "dtype": "f64 ant kinematics / f32 grids", "data": "synthetic",
             "repeats": REPEATS, "ms_per_step_regions": [round(r / K * 1e3, 5) for r in region_s],
             "ms_per_step_spread": round((max(region_s) - min(region_s)) / K * 1e3, 5),
-            "rccl_ranks": (dist.get_world_size() if dist is not None else 1),
+            "rccl_ranks": (dist.get_world_size() if dist is not None else 1),  # ranks of the process group (one per GPU)
+            "collective_backend": (backend if dist is not None else None),   # "nccl" = RCCL; "gloo" = the one-GPU rehearsal
             "env_id_base_per_rank": bases, "n_envs_total": world * E,
+            # per-rank figures, rank order: each rank's OWN median region (before the MAX over ranks), its device, what its
+            # placement tuner chose (and the default pair's time beside it: the untuned figure), what the gather costs it
+            "ms_per_step_per_rank": [round(r["ms_per_step"], 5) for r in per_rank],
+            "device_unique_id_per_rank": [r["device"] for r in per_rank],
+            "placement_chosen_ms_per_rank": [r["placement_chosen_ms"] for r in per_rank],
+            "placement_default_ms_per_rank": [r["placement_default_ms"] for r in per_rank],
+            "gather_overhead_us": [r["gather_overhead_us"] for r in per_rank] if dist is not None else None,
             "gather_self_checks": gather_checks,  # regions whose all-gathered own-shard rows were compared with the local tensors
             "config": {"workload": W_["desc"], "episode_age_steps": args.age, "envs_per_gpu": E, "ants": cfg.n_ants, "grid": [cfg.w, cfg.h],
                        "pheromone_channels": cfg.n_phero, "rocks": cfg.n_rocks, "obs_channels": cfg.n_channels,

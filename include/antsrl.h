@@ -371,13 +371,20 @@ int antsrl_bench_copy(void *dst, const void *src, size_t bytes, void *stream);
  * ranges of 128 MiB or more (what hipMalloc hands a fresh process) the observation write stream and the cell-record
  * gathers alias on the memory channels; with either buffer in pieces of at most 32 MiB they do not — k_perceive 0.167 ms
  * against 0.197 ms at 1024 envs x 512 ants, on every allocation (profiles/r04/placement_probe4*.txt).  The pointer is
- * aligned to the device's allocation granularity (2 MiB); contents are undefined; free with antsrl_mem_free (never hipFree):
- * the physical memory is returned, the virtual range stays reserved for the life of the process (a re-used range can meet
- * stale GPU translations on ROCm 7.2: antsrl_mem.hip).  Returns ANTSRL_E_NOMEM
- * when the device cannot supply the pieces, ANTSRL_E_DEVICE when the runtime lacks the virtual-memory API. */
+ * aligned to the device's allocation granularity (2 MiB); contents are undefined; free with antsrl_mem_free (never hipFree).
+ * antsrl_mem_free waits for the block's device and PARKS the block, still mapped, in a per-device pool; antsrl_mem_alloc hands
+ * a parked block of the same device and (piece-rounded) size back before it maps anything new.  Nothing is unmapped while
+ * the program runs, so no address is ever translated to other memory than it was first mapped to (a range that is unmapped,
+ * freed and reserved again can meet stale GPU translations on ROCm 7.2: antsrl_mem.hip) and the reserved address space is
+ * bounded by the blocks that were alive at once.  antsrl_mem_trim returns the parked blocks' physical memory to the device
+ * (their ranges are retired, never reused); antsrl_mem_stats reports bytes handed out / parked / reserved / retired (any
+ * pointer may be NULL).  Returns ANTSRL_E_NOMEM when the device cannot supply the pieces, ANTSRL_E_DEVICE when the runtime
+ * lacks the virtual-memory API. */
 #define ANTSRL_MEM_PIECE_BYTES ((size_t)16 << 20)
 int antsrl_mem_alloc(size_t bytes, int device, void **ptr);
 int antsrl_mem_free(void *ptr);
+int antsrl_mem_trim(void);
+int antsrl_mem_stats(size_t *live_bytes, size_t *pooled_bytes, size_t *reserved_va_bytes, size_t *retired_va_bytes);
 
 /* Observation tensor format (no reference counterpart: the reference's perception is float64 numpy,
  * cast to float32 by torch.Tensor(state) in the agents, collect_agent_memory.py:194).

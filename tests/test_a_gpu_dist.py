@@ -76,3 +76,34 @@ def test_ranks_on_one_gpu_over_gloo(world):
     out = _run(cmd, env)
     assert out.returncode == 0, out.stdout[-6000:]
     assert all("DIST_GPU_OK %d of %d" % (r, world) in out.stdout for r in range(world)), out.stdout[-4000:]
+
+
+def test_bench_py_with_two_ranks_on_one_gpu():
+    """bench.py ITSELF under torch.distributed.run with two processes — the launch the driver makes on its 8-GPU node, which had
+    never met a second process: per-rank set_device, per-rank tune_placement, shards with their global env ids, the
+    per-step gather with its self-check, the MAX over ranks, the per-rank arrays of the JSON line.  One GPU here, so both ranks
+    sit on device 0 and the transport is gloo (ANTSRL_BENCH_BACKEND / ANTSRL_BENCH_ONE_GPU); no scaling figure is read off it."""
+    import json
+    E, repeats = 96, 2   # (96 envs x 512 ants: the outputs are past vmm.SMALL_BYTES, so the placement tuner really runs)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", ANTSRL_BENCH_BACKEND="gloo", ANTSRL_BENCH_ONE_GPU="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5",
+           "--age", "30", "--repeats", str(repeats), "--envs", str(E)]
+    out = _run(cmd, env)
+    assert out.returncode == 0, out.stdout[-6000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+    assert len(lines) == 1, "rank 0 prints ONE JSON line:\n" + out.stdout[-3000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["rccl_ranks"] == 2 and rec["collective_backend"] == "gloo"
+    assert rec["env_id_base_per_rank"] == [0, E] and rec["n_envs_total"] == 2 * E
+    assert rec["gather_self_checks"] == repeats and rec["scaling"] == "weak"
+    for key in ("ms_per_step_per_rank", "device_unique_id_per_rank", "placement_chosen_ms_per_rank", "placement_default_ms_per_rank",
+                "gather_overhead_us"):
+        assert len(rec[key]) == 2, key
+    assert all(v is not None and v > 0 for v in rec["ms_per_step_per_rank"] + rec["placement_chosen_ms_per_rank"])
+    assert rec["device_unique_id_per_rank"][0] == rec["device_unique_id_per_rank"][1] is not None  # (one GPU)
+    assert max(rec["ms_per_step_per_rank"]) <= rec["ms_per_step"] * 1.0001  # the line's figure is the MAX over the ranks
+    assert rec["value"] == pytest.approx(2 * E * 512 * 20 / (rec["ms_per_step"] * 1e-3 * 20), rel=1e-6)
+    log = os.path.join(ROOT, "gpurun_out", "bench_two_ranks_one_gpu.json")
+    if os.path.isdir(os.path.dirname(log)):
+        open(log, "w").write(lines[0] + "\n")

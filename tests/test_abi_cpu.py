@@ -129,6 +129,24 @@ def test_lds_budget_is_checked(lib):
     assert b"LDS" in lib.antsrl_last_error()
 
 
+def test_reference_seed_limit_is_checked_without_wrapping(lib):
+    """np.random.seed(seed * 5) takes 32 bits (environment_generator.py:55): (episode_seed + env_id_base + n_envs) * 5 must
+    stay below 2^32.  A base past 0xFFFFFFFF / 5 used to make the limit's subtraction wrap: the call was accepted
+    and the seeds of the last environments replayed earlier episodes' streams.  Refused before anything is launched."""
+    from antsrl_amd.config import make_gen
+    n = C.c_size_t()
+    for base, seed in ((900000000, 1), (858993459 - 8, 1), (0, 858993452), (0, 2 ** 33), (0x7fffffff - 8, 0)):
+        cfg = make_cfg(8, 16, 32, 32, env_id_base=base)
+        assert lib.antsrl_workspace_bytes(C.byref(cfg), C.byref(n)) == 0
+        h = C.c_void_p()
+        assert lib.antsrl_create(C.byref(cfg), C.c_void_p(4096), n.value, C.byref(h)) == 0
+        gen = make_gen(wall_density=0.0, rng="reference")
+        rc = lib.antsrl_generate(h, C.byref(gen), C.c_uint64(seed), None)  # (refused: nothing touches the fake workspace)
+        assert rc == -1 and b"np.random.seed" in lib.antsrl_last_error(), (base, seed, lib.antsrl_last_error())
+        lib.antsrl_destroy(h)
+    # (seeds right below the limit are accepted: tests/test_gpu_generate.py runs them on the device)
+
+
 def test_product_never_imports_oracle():
     """The product path must not route through the CPU oracle (or any CPU fallback)."""
     pkg = os.path.join(ROOT, "antsrl_amd")

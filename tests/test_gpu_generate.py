@@ -179,6 +179,15 @@ def test_generate_rejects_bad_wall_parameters():
     g.wall_kind = 7
     with pytest.raises(_lib.AntsrlError, match="wall_kind"):
         env.generate(g, episode_seed=1)
+    # np.random.seed's 32 bits (environment_generator.py:55): the last accepted seed, the first refused one, and a base past
+    # 0xFFFFFFFF / 5 (where the limit's own subtraction used to wrap: ADVICE r4)
+    lim = 0xFFFFFFFF // 5
+    env.generate(cm.make_gen(wall_density=0.0, rng="reference"), episode_seed=lim - 1)
+    with pytest.raises(_lib.AntsrlError, match="np.random.seed"):
+        env.generate(cm.make_gen(wall_density=0.0, rng="reference"), episode_seed=lim)
+    far = BatchedAntsEnv(cm.make_cfg(1, 4, 16, 16, env_id_base=900000000))
+    with pytest.raises(_lib.AntsrlError, match="np.random.seed"):
+        far.generate(cm.make_gen(wall_density=0.0, rng="reference"), episode_seed=1)
 
 
 def test_device_generator_takes_the_reference_walls_generator():

@@ -26,9 +26,13 @@ def test_pieced_memory_round_trip_and_lifetime():
     assert int(w[-1]) == 7
     torch.cuda.synchronize()
     held = torch.cuda.mem_get_info()[0]
-    del w                    # ... the last one releases it: the physical pieces go back to the device
-    gc.collect()
+    del w                    # ... the last one parks the block in the library's pool (still mapped: nothing is unmapped
+    gc.collect()             # while the program runs) ...
     torch.cuda.synchronize()
+    st = [C.c_size_t() for _ in range(4)]
+    assert lib.antsrl_mem_stats(*[C.byref(x) for x in st]) == 0 and st[1].value >= (200 << 20)
+    assert lib.antsrl_mem_trim() == 0   # ... and an explicit trim returns the physical pieces to the device
+    assert lib.antsrl_mem_stats(*[C.byref(x) for x in st]) == 0 and st[1].value == 0
     assert torch.cuda.mem_get_info()[0] - held >= (190 << 20), "the 200 MiB were not returned"
     del free0
     # the C-ABI directly: bad arguments, double free
@@ -57,27 +61,50 @@ def test_env_on_pieced_memory_equals_env_on_torch_memory():
         assert torch.equal(a.read_state(which), b.read_state(which))
 
 
-def test_freed_ranges_never_alias_live_buffers():
-    """antsrl_mem_free retires the virtual range (antsrl_mem.hip): on ROCm 7.2 a re-used range could still be translated to
-    its OLD physical pieces, so that two live buffers aliased each other — seen in 95 of 300 rounds of exactly this loop
-    before the fix (profiles/r04/vmm_stress.py).  Allocate two buffers, fill, cross-copy, check, free; sizes vary."""
+def _alloc_fill_check_free(rounds):
     import torch
     from antsrl_amd import vmm
-    seen = set()
-    for it in range(60):
+    for it in range(rounds):
         n = ((it % 7) * 37 + 70) << 20
         v = vmm.pieced_u8(n, "cuda:0").view(torch.int32)
-        assert v.data_ptr() not in seen, "a virtual range was handed out twice"
-        seen.add(v.data_ptr())
         v.fill_(it + 1)
         other = torch.empty(n // 4, dtype=torch.int32, device="cuda:0").fill_(-(it + 1))
         u = vmm.pieced_u8(n, "cuda:0").view(torch.int32)
+        assert u.data_ptr() != v.data_ptr()
         u.copy_(v)
         u += 1000000
         assert bool((v == it + 1).all()) and bool((u == it + 1 + 1000000).all()) and bool((other == -(it + 1)).all()), it
         del v, u, other
         if it % 3 == 0:
             gc.collect()
+    gc.collect()
+
+
+def test_freed_blocks_are_pooled_and_never_alias_live_buffers():
+    """antsrl_mem_free parks a block — range AND pieces, still mapped — and antsrl_mem_alloc hands it back for the same
+    device and size (antsrl_mem.hip): no address is ever mapped to other memory than it first was.  On ROCm 7.2 a range
+    that was unmapped, freed and reserved again could still be translated to its OLD physical pieces, so that two live
+    buffers aliased each other — 95 of 300 rounds of exactly this loop (profiles/r04/vmm_stress.py); round 4 retired every
+    freed range instead, and the reserved address space grew with every free.  Allocate two buffers, fill,
+    cross-copy, check, free; sizes vary; then: the reserved address space does not grow over 200 more rounds."""
+    import torch
+    from antsrl_amd import _lib
+    lib = _lib.load()
+    st = [C.c_size_t() for _ in range(4)]
+
+    def stats():
+        assert lib.antsrl_mem_stats(*[C.byref(x) for x in st]) == 0
+        return tuple(x.value for x in st)  # live, pooled, reserved, retired
+    _alloc_fill_check_free(21)             # (every size of the cycle has been seen: the pool holds two blocks of each)
+    torch.cuda.synchronize()
+    live0, pooled0, reserved0, retired0 = stats()
+    _alloc_fill_check_free(200)
+    torch.cuda.synchronize()
+    live1, pooled1, reserved1, retired1 = stats()
+    assert reserved1 == reserved0 and retired1 == retired0 and pooled1 == pooled0 and live1 == live0, \
+        "address space / pool grew over 200 alloc-free rounds: %s -> %s" % ((live0, pooled0, reserved0, retired0), (live1, pooled1, reserved1, retired1))
+    assert lib.antsrl_mem_trim() == 0
+    assert stats()[1] == 0
 
 
 def test_tune_placement_leaves_a_clean_handle():
@@ -97,6 +124,9 @@ def test_tune_placement_leaves_a_clean_handle():
     assert BatchedAntsEnv(cm.make_cfg(2, 8, 32, 32)).tune_placement() is None  # (small batches: nothing to alias)
     a.reset(init)
     b.reset(init)
+    from antsrl_amd import _lib
+    with pytest.raises(_lib.AntsrlError, match="right after construction"):  # (it would drop the loaded episode silently)
+        a.tune_placement(age=2, steps=2)
     rot, ph = random_actions(cfg, 5, seed=2)
     for t in range(5):
         for x, y in zip(a.step_update(rot[t], ph[t], None), b.step_update(rot[t], ph[t], None)):

@@ -75,7 +75,16 @@ def test_row_stride_is_validated_and_excludes_the_inloop_policy():
     if p16.query(cm.Q_PERCEIVE_RUN) * 4 > 32:
         pytest.skip("the in-loop policy needs a 32-ant tile per workgroup (tests/alt_paths.sh: ANTSRL_PRC_RUN)")
     p16.reset(synth_init(cfg, seed=1, n_food_discs=3, food_rmin=2, food_rmax=4))
-    LinearPolicy(cfg.pside ** 2 * cfg.n_channels, p16.device, seed=1).attach(p16)
+    # refused when it is CONFIGURED, in either order — not in the middle of a step whose move has already been enqueued
+    pol = LinearPolicy(cfg.pside ** 2 * cfg.n_channels, p16.device, seed=1)
     with pytest.raises(_lib.AntsrlError, match="in-loop policy"):
-        p16.observe()
+        pol.attach(p16)
+    p16.observe()  # (no policy was attached: the padded env still observes)
+    d16 = BatchedAntsEnv(cfg, obs_dtype=torch.bfloat16)
+    d16.reset(synth_init(cfg, seed=1, n_food_discs=3, food_rmin=2, food_rmax=4))
+    pol.attach(d16)
+    assert lib.antsrl_set_obs_row_stride(d16._h, 384) == -4 and b"in-loop policy" in lib.antsrl_last_error()
+    d16.observe()
+    pol.detach(d16)
+    assert lib.antsrl_set_obs_row_stride(d16._h, 384) == 0
     del C
