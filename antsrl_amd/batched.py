@@ -55,7 +55,7 @@ class BatchedAntsEnv:
         pieced_memory: the output buffer (the observation tensor) comes from antsrl_mem_alloc (physical pieces of 16 MiB)
         instead of torch.empty; the workspace stays a torch allocation.  On MI355X the observation kernel runs 15 % apart
         depending on the physical layout of these two buffers; this combination is the fast one on most boxes, two torch
-        allocations are mostly slow (antsrl_amd/vmm.py, profiles/r04/placement_probe*.txt).  tune_placement() measures the
+        allocations are mostly slow (antsrl_amd/vmm.py, profiles/history/r04/placement_probe*.txt).  tune_placement() measures the
         four combinations on the box at hand and keeps the fastest."""
         if obs_dtype not in (torch.float32, torch.bfloat16):
             raise ValueError("obs_dtype must be torch.float32 or torch.bfloat16")

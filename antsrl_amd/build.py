@@ -35,6 +35,17 @@ def hipcc() -> str:
     raise RuntimeError("hipcc not found (needs the ROCm toolchain)")
 
 
+def source_hash() -> str:
+    """sha256 (first 16 hex digits) over the kernel sources and the C-ABI header: what a measurement was taken ON
+    (profiles/traffic_<config>.json records it; bench.py flags PMC figures that pre-date the tree it runs)."""
+    import hashlib
+    h = hashlib.sha256()
+    for path in sorted([os.path.join(CSRC, s) for s in SOURCES] + [os.path.normpath(x) for x in HEADERS]):
+        h.update(os.path.basename(path).encode())
+        h.update(open(path, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def is_stale(path: str = LIB_PATH) -> bool:
     if not os.path.exists(path):
         return True

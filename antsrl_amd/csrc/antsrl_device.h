@@ -87,7 +87,7 @@ struct __align__(16) AntFrame { double cx, cy, ct, st; }; // perception centre, 
 // and theta; the food value and META word of the cell the ant stands on (the deposit cell's record IS the record of the
 // move's mandible decision: one 16-byte load instead of a pheromone read, a dependent food read and an area-bit read);
 // and the move's own per-ant inputs, fetched in front of the update so that their round trip rides with the update's.
-// Round 4 (profiles/r04/um_trace.txt: the workgroup's life is a chain of exposed latencies, not bytes): the move's rotation and
+// Round 4 (profiles/history/r04/um_trace.txt: the workgroup's life is a chain of exposed latencies, not bytes): the move's rotation and
 // its float64 sincos — ~400 VALU instructions that need theta and the action only — are evaluated by the UPDATE while its
 // record load is in flight (`pre`); the env's timestep and reward_primed flag travel along, so that thread 0 of the move
 // has no memory round trip of its own in front of the move's first barrier.

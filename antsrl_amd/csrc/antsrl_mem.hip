@@ -6,7 +6,7 @@
 // stream of 1372-byte rows, 702 464 bytes from one environment to the next) and the workspace's cell records (the
 // gathers).  When both lie in physically contiguous ranges of 128 MiB or more — what hipMalloc hands a fresh process —
 // the streams alias on the memory channels: k_perceive 0.197 ms at c3.  With the observation tensor in pieces of <= 32 MiB
-// it is 0.167-0.174 ms on nearly every allocation (profiles/r04/placement_probe4*.txt: pieces of 2 / 8 / 32 MiB fast,
+// it is 0.167-0.174 ms on nearly every allocation (profiles/history/r04/placement_probe4*.txt: pieces of 2 / 8 / 32 MiB fast,
 // 128 / 256 / 512 / 1024 MiB slow; hipExtMallocWithFlags' fully contiguous memory was 25 % slower still,
 // profiles/r03/box_state_probe3.txt).  Not a law: BOTH buffers pieced was slower again, and some processes' first
 // allocations stay slow either way, which is why the host side measures (BatchedAntsEnv.tune_placement,

@@ -4,7 +4,7 @@ On MI355X the physical layout of the step's two big buffers — the workspace's 
 is worth 15 % of the observation kernel: hipMalloc (what torch.empty ends in) hands a fresh process physically contiguous
 ranges of hundreds of MiB, on which the observation write stream and the record gathers alias on the memory channels
 (k_perceive 0.197 ms at c3); with the observation tensor in pieces of <= 32 MiB it takes 0.167-0.174 ms on nearly every
-allocation (profiles/r04/placement_probe4*.txt; BatchedAntsEnv.tune_placement measures the box at hand).  `pieced_u8(nbytes, device)` is a uint8 tensor over such memory.  PyTorch stays
+allocation (profiles/history/r04/placement_probe4*.txt; BatchedAntsEnv.tune_placement measures the box at hand).  `pieced_u8(nbytes, device)` is a uint8 tensor over such memory.  PyTorch stays
 plumbing: the tensor wraps the pointer through `__cuda_array_interface__`."""
 from __future__ import annotations
 

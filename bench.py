@@ -501,9 +501,14 @@ def main():
             # PMC-derived HBM bytes per launch: NOT measured in this run (rocprofv3 --pmc needs its own passes,
             # profiles/history/pmc_traffic.sh); the record names the profile it came from
             traffic = traffic_rec.get(names[dom])
+            # the counters are only as current as the tree they were taken on: flagged when the kernel sources have changed since
+            from antsrl_amd.build import source_hash
+            traffic_stale = traffic_rec.get("_source_sha16") != source_hash() if traffic_rec else None
             roofline = dict(bound="hbm", kernel=names[dom], achieved=round(achieved, 1), peak=HBM_PEAK_GBS,
                             unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic,
                             traffic_source=(traffic_rec.get("_source") if traffic is not None else None),
+                            traffic_stale=(traffic_stale if traffic is not None else None),
+                            traffic_device=(traffic_rec.get("_device") if traffic is not None else None),
                             algorithmic_bytes_per_launch=ab[dom] * E,
                             kernel_ms={names[k]: round(v, 4) for k, v in kern.items()})
             # the WHOLE step against the roofline: the algorithmic bytes of every kernel the step actually launches
@@ -513,7 +518,8 @@ def main():
             roofline["step_achieved"] = round(step_bytes / (elapsed / K) / 1e9, 1)
             roofline["step_frac"] = round(step_bytes / (elapsed / K) / 1e9 / HBM_PEAK_GBS, 4)
             step_traffic = [traffic_rec.get(names[k]) for k in kern]
-            if traffic_rec and all(v is not None for v in step_traffic):
+            if traffic_rec and all(v is not None for v in step_traffic) and not traffic_stale:
+                # (only from counters taken on THIS tree: a stale figure beside a live time would mix two kernels)
                 # real HBM bytes of one whole step (PMC, every kernel of the step) over the measured step time
                 roofline["step_real_traffic_gbs"] = round(sum(step_traffic) / (elapsed / K) / 1e9, 1)
         else:

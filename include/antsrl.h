@@ -370,7 +370,7 @@ int antsrl_bench_copy(void *dst, const void *src, size_t bytes, void *stream);
  * physical layout of these two buffers is worth 15 % of the observation kernel: when both lie in physically contiguous
  * ranges of 128 MiB or more (what hipMalloc hands a fresh process) the observation write stream and the cell-record
  * gathers alias on the memory channels; with either buffer in pieces of at most 32 MiB they do not — k_perceive 0.167 ms
- * against 0.197 ms at 1024 envs x 512 ants, on every allocation (profiles/r04/placement_probe4*.txt).  The pointer is
+ * against 0.197 ms at 1024 envs x 512 ants, on every allocation (profiles/history/r04/placement_probe4*.txt).  The pointer is
  * aligned to the device's allocation granularity (2 MiB); contents are undefined; free with antsrl_mem_free (never hipFree).
  * antsrl_mem_free waits for the block's device and PARKS the block, still mapped, in a per-device pool; antsrl_mem_alloc hands
  * a parked block of the same device and (piece-rounded) size back before it maps anything new.  Nothing is unmapped while

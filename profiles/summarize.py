@@ -72,6 +72,14 @@ for cfg in ("c3", "c2", "c4", "c5"):
     if per:
         summary[cfg] = per
         traffic = {k: int((2 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024) for k, d in per.items() if "FETCH_SIZE" in d and "WRITE_SIZE" in d}
+        metas = []
+        for cname in ("fetch", "write"):
+            mp = os.path.join(ROOT, "gpurun_out", "pmc_%s_%s.meta.json" % (cfg, cname))
+            if os.path.exists(mp):
+                metas.append(json.load(open(mp)))
+        if metas and all(m == metas[0] for m in metas):  # (both passes on one tree and one device)
+            traffic["_source_sha16"] = metas[0]["source_sha16"]
+            traffic["_device"] = metas[0]["device"]
         traffic["_source"] = "profiles/%s/pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, %s; steady regime: bench.py ages the episode 400 steps before the warm-up)" % (rnd, cfg)
         json.dump(traffic, open(os.path.join(ROOT, "profiles", "traffic_%s.json" % cfg), "w"), indent=1, sort_keys=True)
 json.dump(summary, open(os.path.join(out, "pmc_summary.json"), "w"), indent=1, sort_keys=True)
