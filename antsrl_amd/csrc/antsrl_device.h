@@ -91,6 +91,7 @@ struct __align__(16) AntFrame { double cx, cy, ct, st; }; // perception centre, 
 // its float64 sincos — ~400 VALU instructions that need theta and the action only — are evaluated by the UPDATE while its
 // record load is in flight (`pre`); the env's timestep and reward_primed flag travel along, so that thread 0 of the move
 // has no memory round trip of its own in front of the move's first barrier.
+#define UMFWD_WIN 0x100
 struct UmFwd {
     double x, y, th;
     double th_new, sn, cs; // pre: theta after the rotation, its sine and cosine (RL_api.py:190-196)
@@ -101,6 +102,10 @@ struct UmFwd {
     int pre;      // 1: th_new / sn / cs are valid
     int has_rot;  // the step rotates (a rotation tensor was passed)
     int ts;       // the env's timestep after the update
+    // m, bit 8 (UMFWD_WIN): this ant is the last-writer-wins winner of its cell in the update's hash (the highest ant index
+    // standing on the cell).  The move's food exchange resolves duplicates over the SAME cells (prev := cur in the update) by
+    // the same rule: the verdict is forwarded and the move builds no table of its own (round 5; it shares the mandible
+    // flag's register — one more live VGPR spilled in the explicit-sweep variant of the kernel)
     uint8_t primed; // reward_primed[e] as it stood at the launch
     uint32_t frm_off; // LDS byte offset of the [T][2] doubles where the update parks cos / sin(theta + pi/2) for the frame
 };

@@ -72,7 +72,7 @@ __device__ __forceinline__ void move_body(const KP &p, const int e, const int8_t
         // handed over in registers — the same values, one memory round trip less in front of the dependent food read)
         if (fw) { // (k_update_move: no global load at all in front of the move's first barrier)
             h_x = fw->x; h_y = fw->y; h_th = fw->th;
-            h_hold = fw->hold; h_m = fw->m; h_rot = fw->rot; h_pa = fw->pa;
+            h_hold = fw->hold; h_m = fw->m & 1; h_rot = fw->rot; h_pa = fw->pa;
             h_cprev = frec_xy(p, (int)fw->x, (int)fw->y);
             // The record was loaded by the update before its anthill collect ran.  Food on the anthill area is all zero once
             // the collect is done (anthill.py:41-46; the handle only defers an update that needs no full-grid collect), and
@@ -92,7 +92,10 @@ __device__ __forceinline__ void move_body(const KP &p, const int e, const int8_t
             }
         }
     }
-    if (do_step)
+    // (k_update_move: the update of the same launch has resolved last-writer-wins over exactly these cells — prev := cur, so
+    //  the food cell of the exchange is the deposit cell — and hands every ant its verdict, UmFwd::win: no table, no
+    //  inserts, and none of the move's barriers, which exist for the table alone; profiles/r04/um_trace_final.txt slots 10-12)
+    if (do_step && !fw)
         for (int h = tid; h < p.HT; h += T) {
             hkeys[h] = HASH_EMPTY;
             hvals[h] = 0u;
@@ -108,7 +111,9 @@ __device__ __forceinline__ void move_body(const KP &p, const int e, const int8_t
         }
         if (do_step && done) done[e] = (uint8_t)(p.max_time == (fw ? fw->ts : p.s.timestep[e])); // RL_api.py:200
     }
-    __syncthreads();
+    if (!fw) __syncthreads();
+    else __builtin_amdgcn_sched_barrier(0); // (no barrier, but nothing of the phases below is hoisted above this point either:
+                                            //  the explicit-sweep variant of k_update_move spills three more VGPRs otherwise)
     if (fw) UM_STAMP(10);
 
     if (do_step) {
@@ -148,17 +153,18 @@ __device__ __forceinline__ void move_body(const KP &p, const int e, const int8_t
             cprevs[i] = cprev;
             tmp_q[i] = q;
             tmp_d[i] = dropped - taken;
+            if (fw) break; // (one ant per thread: a single pass, known at compile time; its slots of the scratch arrays are its own)
             lww_insert(hkeys, hvals, (uint32_t)p.HT - 1, cprev, (uint32_t)i);
-            if (fw) break; // (one ant per thread: a single pass, known at compile time)
         }
-        __syncthreads();
+        if (!fw) __syncthreads();
+        else __builtin_amdgcn_sched_barrier(0);
         if (fw) UM_STAMP(11);
         // ---- phase 1b: ants.py:116 `qte[cell] += dropped - taken`, last ant on a cell wins
         for (int i = tid; i < N; i += T) {
             const uint32_t cprev = cprevs[i];
             const float delta = tmp_d[i];
             int32_t dirty = -1;
-            if (delta != 0.0f && lww_winner(hkeys, hvals, (uint32_t)p.HT - 1, cprev) == (uint32_t)i) {
+            if (delta != 0.0f && (fw ? (fw->m & UMFWD_WIN) != 0 : lww_winner(hkeys, hvals, (uint32_t)p.HT - 1, cprev) == (uint32_t)i)) {
                 food[cprev] = tmp_q[i] + delta;
                 // (on the anthill area?  the record's own META word says so: cprev is a record index, not a cell id)
                 if (__float_as_uint((&food[cprev])[1]) & META_AREA) dirty = (int32_t)cprev;

@@ -243,7 +243,9 @@ __device__ __forceinline__ void update_one_body(const KP &p, const int e, const 
     }
     double gain = 0.0;
     if (on) {
-        if (lww_winner(hkeys, hvals, (uint32_t)p.HT - 1, cell) == (uint32_t)tid) {
+        const bool winner = lww_winner(hkeys, hvals, (uint32_t)p.HT - 1, cell) == (uint32_t)tid;
+        if (fw && winner) fw->m |= UMFWD_WIN; // (the move's food exchange is decided over the same cells by the same rule)
+        if (winner) {
             if (!p.scaled) {
 #pragma unroll
                 for (int c = 0; c < C; ++c) {
