@@ -446,8 +446,22 @@ extern "C" int antsrl_debug_read_prc_trace(uint32_t *dst, int n_waves)
 // (float32 7x7x7: 343 -> 352 elements = 11 lines): every 2-row group is then whole lines of this wave's own, copied out
 // with aligned 16-byte stores only — no misalignment, no edge store, no line shared with another wave.  The padding
 // elements are written as zeros.  Same values in the same [E][N][P][P][K] positions; the dense layout is the default.
+// Residency is set by the SCALAR registers here: 256-thread workgroups are admitted per CU up to
+// floor(800 / (ceil(sgpr / 16) * 16 + 16)) (MI355X_MICROARCH.md, "Residency and cooperative launch": <= 80 SGPRs -> 8,
+// 82-96 -> 7, 98+ -> 6).  Left alone the compiler takes 102-106 SGPRs — six workgroups per CU whatever the 66-70 VGPRs would
+// allow (rounds 2-4 read "7 waves per SIMD" off the VGPR count; the c5 time line's "5.9 workgroups per CU" was this limit).
+// Capped at 96 (2-8 of them spilled to VGPR lanes, no vector spill) with the vector budget of seven waves per SIMD (72):
+// SEVEN workgroups per CU for real — same-device A/B, ms/step: c3 0.1985 -> 0.1957, c5 0.0847 -> 0.0827, act-only 0.0752 ->
+// 0.0745, c2 / c4 +-0 (profiles/r05/sgpr_cap_ab.txt).  Eight (cap 80 + 64 VGPRs) spills vector registers and loses 4-11 %.
+#ifndef PRC_SGPR_CAP
+#define PRC_SGPR_CAP 96
+#endif
+#ifndef PRC_MIN_WAVES
+#define PRC_MIN_WAVES 7
+#endif
+#define PRC_SGPR_ATTR __attribute__((amdgpu_num_sgpr(PRC_SGPR_CAP)))
 template <int LAYOUT, bool OBS16, bool ILV, bool HAS_OBS, bool POLICY = false, bool PAD = false>
-__global__ void __launch_bounds__(PRC_TPB, 4)
+__global__ void __launch_bounds__(PRC_TPB, PRC_MIN_WAVES) PRC_SGPR_ATTR
 k_perceive(const KP p, const float *__restrict__ cells, float *__restrict__ obs, float *__restrict__ agent_state,
            float *__restrict__ reward, const int flags, const uint32_t seq, const int run, const int nseg, const PolArgs pol,
            const uint32_t pitch_arg)

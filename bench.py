@@ -104,14 +104,22 @@ class HipEvents:
 
 
 def device_identity(torch, index):
-    """What tells one MI355X from another across runs: the KFD unique id of the device (the figure `rocm-smi --showuniqueid`
-    prints; read from the topology, matched through the PCI address), else the uuid / PCI address torch reports."""
-    pci = None
+    """What tells one MI355X from another across runs: the device's unique id (the figure `rocm-smi --showuniqueid` prints).
+    torch reports it as the device uuid — the id's sixteen hex digits as ASCII bytes; the KFD topology is the fallback."""
+    props = None
     try:
         props = torch.cuda.get_device_properties(index)
+        raw = bytes.fromhex(str(props.uuid).replace("-", ""))
+        txt = raw.decode("ascii")
+        int(txt, 16)
+        return "0x" + txt.lower()
+    except Exception:
+        pass
+    pci = None
+    try:
         pci = "%04x:%02x:%02x" % (getattr(props, "pci_domain_id", 0), props.pci_bus_id, props.pci_device_id)
     except Exception:
-        props = None
+        pass
     try:
         base = "/sys/class/kfd/kfd/topology/nodes"
         for node in sorted(os.listdir(base)):
