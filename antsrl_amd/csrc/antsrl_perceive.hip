@@ -300,7 +300,9 @@ __host__ __device__ __forceinline__ PrcOff prc_offsets(int run, int PP, int K, i
     o.wave0 = (uint32_t)(32 * (size_t)(R > 0 ? R : 1));
     o.frame = 0;
     o.rm = (uint32_t)(sizeof(AntFrame) * (size_t)run);
-    o.stage = (uint32_t)align_up(o.rm + 4 * (size_t)run, 16);
+    // (no rocks: no rock masks — 128 bytes per workgroup that decide the in-loop policy launch's residency: its tile image
+    //  brings a workgroup to 23 488 bytes with them, 23 360 without, and the CU's 160 KB admit SEVEN workgroups up to 23 408)
+    o.stage = (uint32_t)align_up(o.rm + (R > 0 ? 4 * (size_t)run : 0), 16);
     const size_t rowf = (size_t)PP * K;
     o.stride = (uint32_t)((2 * rowf + 32 + 3) / 4 * 4); // floats: misalignment / carry (< one 128-byte line) + two rows
     if (2 * pitch > o.stride) o.stride = 2 * pitch;     // padded rows (PAD): two rows at the observation's row pitch
@@ -628,7 +630,7 @@ k_perceive(const KP p, const float *__restrict__ cells, float *__restrict__ obs,
                     if (border || dx * dx + dy * dy < rr * rr) rm |= 1u << q;
                 }
             }
-            rmask[lane] = rm;
+            if (R > 0) rmask[lane] = rm;
         }
     }
     PRC_STAMP(1);
