@@ -697,8 +697,8 @@ k_perceive(const KP p, const float *__restrict__ cells, float *__restrict__ obs,
             } else {                                                                                     \
                 ix = wrap_index(ix, W); iy = wrap_index(iy, H);                                          \
             }                                                                                            \
-            GRP.ix[u] = ix; GRP.iy[u] = iy;                                                              \
             GRP.cell[u] = PRC_SLOT(ix, iy);                                                              \
+            if (!ILV) GRP.pc[u] = (uint32_t)(ix * H + iy); /* the row-major pheromone buffers' index */  \
         }                                                                                                \
         _Pragma("unroll") for (int u = 0; u < PRC_UNROLL; ++u)                                           \
         {                                                                                                \
@@ -707,7 +707,7 @@ k_perceive(const KP p, const float *__restrict__ cells, float *__restrict__ obs,
                 const stream_f4 t = PRC_LOAD4(ph + (size_t)gc_ * 4);                                     \
                 GRP.pv[u][0] = t.x; GRP.pv[u][1] = t.y; GRP.fd[u] = t.z; GRP.mt[u] = __float_as_uint(t.w); \
             } else {                                                                                     \
-                const uint32_t pc_ = abl_gather ? (uint32_t)lane : (uint32_t)__shfl(GRP.ix[u] * H + GRP.iy[u], src_lane); \
+                const uint32_t pc_ = abl_gather ? (uint32_t)lane : (uint32_t)__shfl((int)GRP.pc[u], src_lane); \
                 const float2 t = *reinterpret_cast<const float2 *>(ph + (size_t)pc_ * 2);                \
                 const float2 f = *reinterpret_cast<const float2 *>(fm + (size_t)gc_ * 2);                \
                 GRP.pv[u][0] = t.x; GRP.pv[u][1] = t.y; GRP.fd[u] = f.x; GRP.mt[u] = __float_as_uint(f.y); \
@@ -715,9 +715,10 @@ k_perceive(const KP p, const float *__restrict__ cells, float *__restrict__ obs,
         }                                                                                                \
     }
     // one group of PRC_UNROLL ants in flight: cell indices and the gathered record of this lane's cell
+    // (the cell's coordinates are not kept: only the rock test needs them, for the few cells whose ant has a rock in reach —
+    //  recomputed there from the frame, the same operations on the same values; four registers per set less)
     struct PrcGrp {
-        uint32_t cell[PRC_UNROLL], mt[PRC_UNROLL];
-        int ix[PRC_UNROLL], iy[PRC_UNROLL];
+        uint32_t cell[PRC_UNROLL], mt[PRC_UNROLL], pc[ILV ? 1 : PRC_UNROLL];
         float pv[PRC_UNROLL][C], fd[PRC_UNROLL];
     };
     PrcGrp gA, gB, gC;
@@ -775,12 +776,25 @@ k_perceive(const KP p, const float *__restrict__ cells, float *__restrict__ obs,
                 if (LAYOUT == PLAYOUT_DEFAULT_ROCKS) {
                     uint32_t rm = mask_q ? rmask[j] : 0u;
                     bool any = false;
-                    while (rm) {
-                        const int r = __builtin_ctz(rm);
-                        rm &= rm - 1;
-                        const double vx = (double)g.ix[u] - rock[4 * r + 0];
-                        const double vy = (double)g.iy[u] - rock[4 * r + 1];
-                        any |= vx * vx + vy * vy < rock[4 * r + 3]; // == sqrt(d2) < radius, see sqrt_lt_threshold
+                    if (rm) { // (rare: a rock within reach of this ant's patch)
+                        const AntFrame fr = frames[j];
+                        int ix = (int)rint((fr.ct * of_px - fr.st * of_py) + fr.cx); // as in PRC_FETCH (RL_api.py:110-119)
+                        int iy = (int)rint((fr.st * of_px + fr.ct * of_py) + fr.cy);
+                        if (wrap_pow2) {
+                            ix &= W - 1; iy &= H - 1;
+                        } else if (wrap_fast) {
+                            ix = (int)min(min((uint32_t)ix, (uint32_t)(ix + W)), (uint32_t)(ix - W));
+                            iy = (int)min(min((uint32_t)iy, (uint32_t)(iy + H)), (uint32_t)(iy - H));
+                        } else {
+                            ix = wrap_index(ix, W); iy = wrap_index(iy, H);
+                        }
+                        while (rm) {
+                            const int r = __builtin_ctz(rm);
+                            rm &= rm - 1;
+                            const double vx = (double)ix - rock[4 * r + 0];
+                            const double vy = (double)iy - rock[4 * r + 1];
+                            any |= vx * vx + vy * vy < rock[4 * r + 3]; // == sqrt(d2) < radius, see sqrt_lt_threshold
+                        }
                     }
                     v_rock = any ? 1.0f : 0.0f;
                 }
