@@ -462,9 +462,20 @@ extern "C" int antsrl_debug_read_prc_trace(uint32_t *dst, int n_waves)
 #define PRC_MIN_WAVES 7
 #endif
 #define PRC_SGPR_ATTR __attribute__((amdgpu_num_sgpr(PRC_SGPR_CAP)))
+#ifdef ANTSRL_PROFILING
+// Placement probe (profiles/r05/env_pitch_probe.py): extra bytes between two environments' blocks of observation rows — the
+// caller's buffer is E * (N * row bytes + pad) then.  A pitch knob for measurements; the product's tensor is dense.
+__device__ uint32_t g_prc_env_pad;
+extern "C" int antsrl_debug_set_obs_env_pad(uint32_t bytes)
+{
+    if (bytes % 16) return ANTSRL_E_INVALID;
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_prc_env_pad), &bytes, sizeof(bytes)) == hipSuccess ? ANTSRL_OK : ANTSRL_E_DEVICE;
+}
+#endif
+
 template <int LAYOUT, bool OBS16, bool ILV, bool HAS_OBS, bool POLICY = false, bool PAD = false>
 __global__ void __launch_bounds__(PRC_TPB, PRC_MIN_WAVES) PRC_SGPR_ATTR
-k_perceive(const KP p, const float *__restrict__ cells, float *__restrict__ obs, float *__restrict__ agent_state,
+k_perceive(const KP p, const float *__restrict__ cells, float *__restrict__ obs_arg, float *__restrict__ agent_state,
            float *__restrict__ reward, const int flags, const uint32_t seq, const int run, const int nseg, const PolArgs pol,
            const uint32_t pitch_arg)
 {
@@ -503,6 +514,11 @@ k_perceive(const KP p, const float *__restrict__ cells, float *__restrict__ obs,
         }
         e = env_of_block(e, p.E, seq); // (odd observations from the other end: antsrl_util.h)
     }
+#ifdef ANTSRL_PROFILING
+    float *__restrict__ obs = HAS_OBS ? reinterpret_cast<float *>(reinterpret_cast<unsigned char *>(obs_arg) + (size_t)e * g_prc_env_pad) : obs_arg;
+#else
+    float *__restrict__ obs = obs_arg;
+#endif
     const PrcOff lo = prc_offsets(run, PP, K, R, nwaves, POLICY, PAD ? pitch_arg : 0u);
     double *rock = (double *)(smem + lo.rock);
     unsigned char *wbase = smem + lo.wave0 + (size_t)wave * lo.per_wave;
