@@ -143,20 +143,28 @@ class BatchedAntsEnv:
         if pitch != row:
             _lib.check(self.lib.antsrl_set_obs_row_stride(self._h, pitch), "set_obs_row_stride")
 
-    def tune_placement(self, age: int = 150, steps: int = 30, verbose: bool = False, extra_outputs: int = 4):
+    def tune_placement(self, age: int = 150, steps: int = 30, verbose: bool = False, extra_outputs: int = 4,
+                       walk_spacers: int = 3, spacer_gib: float = 40.0):
         """Pick the (workspace, output buffer) pair whose PHYSICAL placement steps fastest.  Call it right after construction,
         BEFORE reset() / generate() and before anything is attached to the handle: it runs scratch episodes (device
         generator + uniform random actions), may re-create the handle on another workspace, and leaves it to be reset.
 
-        Why: on MI355X the observation kernel runs up to 15 % apart depending on where the observation tensor and the
-        workspace lie in physical memory: two hipMalloc ranges are usually the slow pair, one of the two
-        on antsrl_mem_alloc pieces usually a fast one — usually, and which of the two depends on the box.  So the four
-        combinations {torch.empty, pieced} x {torch.empty, pieced} are each stepped `steps` times at the same point of the same
-        scratch episode and the fastest pair is kept; the others are freed.  Then `extra_outputs` more output buffers of the
-        default kind (fresh physical pieces) are tried on the torch workspace: on a device where that pair is the fast one, one
-        allocation in four or five still lands 4-8 % off (profiles/r04/box_id.txt), and another draw usually does not.
-        One-off cost ~0.4 s at c3.  Returns the ms/step figures, the four pairs first (None for small batches, where there is
-        nothing to alias)."""
+        Why (profiles/r05/two_colour.txt, region_map.txt): the device's memory falls into a few large
+        ZONES (tens of GB each), and the observation kernel runs 15 % slower when the observation tensor — a streaming write
+        — and the workspace's cell records — scattered gathers — lie in the SAME zone (two levels, 0.169 / 0.197 ms at c3;
+        every buffer keeps its level against every workspace of one zone and has the opposite level against a workspace of
+        another zone).  Zones cannot be seen (no call returns a physical address) but they can be measured.  In a fresh
+        process hipMalloc (torch.empty) and antsrl_mem_alloc draw from different zones, so the env's default pair
+        (workspace torch.empty, outputs pieced) is a fast one and two torch.empty buffers the slow one — until other
+        allocations have moved either allocator into the other's zone.  So: the four {torch.empty, pieced} x {torch.empty,
+        pieced} pairs and `extra_outputs` more draws of the default kind are each stepped `steps` times at the same point of
+        a scratch episode; if they show BOTH levels (a spread of 6 % or more) the fastest pair is on the fast one and is
+        kept.  If every pair sits on ONE level (all fast — or all in one zone), the tuner walks: up to `walk_spacers` times
+        it takes a `spacer_gib` GiB spacer (so that the next buffers come from further into the device's memory), draws
+        one more output buffer of each kind and measures; it stops as soon as both levels have been seen.  Everything but
+        the kept pair is freed at the end (pieced buffers go back to the library's pool, spacers to the driver).
+        One-off cost ~0.4 s at c3 (plus ~0.1 s per walk step).  Returns the ms/step figures, the four pairs first (None for
+        small batches, where there is nothing to alias)."""
         if self._out_total < vmm.SMALL_BYTES:
             return None
         if self._loaded:
@@ -217,17 +225,40 @@ class BatchedAntsEnv:
                     pairs.append((self._ws, self._out_flat))
                     times.append(measure())
                     labels.append("ws torch / out pieced (draw %d)" % (k + 2))
+            # Both levels seen?  If not, walk further into the device's memory until a buffer of another zone turns up.
+            spacers = []
+            walked = 0
+            while self._pieced and walked < int(walk_spacers) and max(times) < 1.06 * min(times):
+                free_b = torch.cuda.mem_get_info(dev)[0]
+                want = int(min(spacer_gib * 2 ** 30, free_b / 3))
+                if want < (4 << 30):
+                    break
+                try:
+                    spacers.append(torch_u8(want))
+                except RuntimeError:
+                    break
+                walked += 1
+                if self._ws.data_ptr() != own_ws.data_ptr():
+                    self._make_handle(own_ws)
+                scratch_episode()
+                for kind, mk in (("pieced", lambda: vmm.empty_u8(n_out, dev)), ("torch", lambda: torch_u8(n_out))):
+                    self._bind_outputs(mk().zero_())
+                    pairs.append((self._ws, self._out_flat))
+                    times.append(measure())
+                    labels.append("ws torch / out %s (walk %d: +%.0f GiB)" % (kind, walked, sum(x.numel() for x in spacers) / 2 ** 30))
             best = min(range(len(times)), key=times.__getitem__)
             if verbose:
                 print("tune_placement: ms/step per (workspace, outputs) pair %s -> %d" % (["%.4f" % t for t in times], best))
             ws, out = pairs[best]
-            del pairs
+            del pairs, spacers
+            torch.cuda.empty_cache()  # (the spacers and the losing torch buffers go back to the driver)
             if ws.data_ptr() != self._ws.data_ptr():
                 self._make_handle(ws)
             self._bind_outputs(out)
             self._out_flat.zero_()
             del own_ws, own_out, ws, out
-        self.placement_trials = dict(ms_per_step=[round(t, 5) for t in times], chosen=best, pairs=labels)
+        self.placement_trials = dict(ms_per_step=[round(t, 5) for t in times], chosen=best, pairs=labels,
+                                     both_levels_seen=bool(max(times) >= 1.06 * min(times)), walk_steps=walked)
         self._loaded = None  # (the scratch episodes were the tuner's own: the handle is as new)
         return times
 

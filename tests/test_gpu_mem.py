@@ -118,9 +118,15 @@ def test_tune_placement_leaves_a_clean_handle():
     cfg = cm.make_cfg(128, 384, 256, 256, n_rocks=4, deposit_strength=256.0)
     init = synth_init(cfg, seed=3)
     a, b = BatchedAntsEnv(cfg), BatchedAntsEnv(cfg)
-    times = a.tune_placement(age=20, steps=8)
+    times = a.tune_placement(age=20, steps=8, walk_spacers=0)
     assert times is not None and len(times) == 8 and a.placement_trials["chosen"] in range(8)  # (four pairs + four more draws)
-    assert len(BatchedAntsEnv(cfg).tune_placement(age=10, steps=4, extra_outputs=0)) == 4
+    assert len(BatchedAntsEnv(cfg).tune_placement(age=10, steps=4, extra_outputs=0, walk_spacers=0)) == 4
+    # the walk (taken when every pair sat on one level): one 4 GiB spacer, two more draws; everything but the kept pair freed
+    w = BatchedAntsEnv(cfg)
+    tw = w.tune_placement(age=10, steps=4, extra_outputs=0, walk_spacers=1, spacer_gib=4.0)
+    assert len(tw) in (4, 6) and w.placement_trials["walk_steps"] == (len(tw) - 4) // 2
+    assert w.placement_trials["both_levels_seen"] == (max(tw) >= 1.06 * min(tw))
+    del w
     assert BatchedAntsEnv(cm.make_cfg(2, 8, 32, 32)).tune_placement() is None  # (small batches: nothing to alias)
     a.reset(init)
     b.reset(init)
