@@ -362,6 +362,18 @@ extern "C" int antsrl_create(const AntsCfg *cfg, void *workspace, size_t workspa
 
 extern "C" void antsrl_destroy(AntsHandle *h) { delete h; }
 
+#ifdef ANTSRL_PROFILING
+// Zone probe (profiles/r05/split_workspace_probe.py): the interleaved cell records at a caller-supplied address instead of
+// inside the workspace — call right after antsrl_create, before antsrl_reset / antsrl_generate.  16 * E * W * H bytes.
+extern "C" int antsrl_debug_set_cells_base(AntsHandle *h, void *cells)
+{
+    if (!h || !cells || h->p.ps != 4 || h->p.fs != 4) return ANTSRL_E_INVALID;
+    h->p.s.phero[0] = h->p.s.phero[1] = (float *)cells;
+    h->p.s.food = (float *)cells + 2;
+    return ANTSRL_OK;
+}
+#endif
+
 extern "C" int antsrl_reset(AntsHandle *h, const AntsInit *init, void *stream)
 {
     if (!h || !init) return fail(ANTSRL_E_INVALID, "NULL handle or init");
