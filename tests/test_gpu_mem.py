@@ -125,7 +125,8 @@ def test_tune_placement_leaves_a_clean_handle():
     w = BatchedAntsEnv(cfg)
     tw = w.tune_placement(age=10, steps=4, extra_outputs=0, walk_spacers=1, spacer_gib=4.0)
     assert len(tw) in (4, 6) and w.placement_trials["walk_steps"] == (len(tw) - 4) // 2
-    assert w.placement_trials["both_levels_seen"] == (max(tw) >= 1.06 * min(tw))
+    ok = [t for t in tw if t < 1.25 * min(tw)]
+    assert w.placement_trials["both_levels_seen"] == (max(ok) >= 1.06 * min(ok))
     del w
     assert BatchedAntsEnv(cm.make_cfg(2, 8, 32, 32)).tune_placement() is None  # (small batches: nothing to alias)
     a.reset(init)
