@@ -144,7 +144,7 @@ class BatchedAntsEnv:
             _lib.check(self.lib.antsrl_set_obs_row_stride(self._h, pitch), "set_obs_row_stride")
 
     def tune_placement(self, age: int = 150, steps: int = 30, verbose: bool = False, extra_outputs: int = 4,
-                       walk_spacers: int = 3, spacer_gib: float = 40.0):
+                       walk_spacers: int = 3, spacer_gib: float = 40.0, force_walk: bool = False):
         """Pick the (workspace, output buffer) pair whose PHYSICAL placement steps fastest.  Call it right after construction,
         BEFORE reset() / generate() and before anything is attached to the handle: it runs scratch episodes (device
         generator + uniform random actions), may re-create the handle on another workspace, and leaves it to be reset.
@@ -160,8 +160,9 @@ class BatchedAntsEnv:
         pieced} pairs and `extra_outputs` more draws of the default kind are each stepped `steps` times at the same point of
         a scratch episode; if they show BOTH levels (a spread of 6 % or more) the fastest pair is on the fast one and is
         kept.  If every pair sits on ONE level (all fast — or all in one zone), the tuner walks: up to `walk_spacers` times
-        it takes a `spacer_gib` GiB spacer (so that the next buffers come from further into the device's memory), draws
-        one more output buffer of each kind and measures; it stops as soon as both levels have been seen.  Everything but
+        it takes a `spacer_gib` GiB spacer from each allocator (so that the next buffers come from further into the device's
+        memory), draws one more output buffer of each kind and one more workspace and measures; it stops as soon as both
+        levels have been seen (`force_walk`: walk regardless — tests).  Everything but
         the kept pair is freed at the end (pieced buffers go back to the library's pool, spacers to the driver).
         One-off cost ~0.4 s at c3 (plus ~0.1 s per walk step).  Returns the ms/step figures, the four pairs first (None for
         small batches, where there is nothing to alias)."""
@@ -233,16 +234,21 @@ class BatchedAntsEnv:
                 #  0.233s on a device whose every buffer sat on the slow level, under rocprofv3)
                 ok = [t for t in ts if t < 1.25 * min(ts)]
                 return max(ok) >= 1.06 * min(ok)
-            while self._pieced and walked < int(walk_spacers) and not both_levels(times):
+            while self._pieced and walked < int(walk_spacers) and (force_walk or not both_levels(times)):
+                # one step of the walk: a spacer from EACH allocator (hipMalloc and the virtual-memory one draw from
+                # different ends of the device's memory: profiles/r05/two_colour.txt), then one more output buffer of each
+                # kind against the env's own workspace, and the env's own output buffer against one more torch workspace
                 free_b = torch.cuda.mem_get_info(dev)[0]
-                want = int(min(spacer_gib * 2 ** 30, free_b / 3))
+                want = int(min(spacer_gib * 2 ** 30, free_b / 5))
                 if want < (4 << 30):
                     break
                 try:
                     spacers.append(torch_u8(want))
-                except RuntimeError:
+                    spacers.append(vmm.empty_u8(want, dev))
+                except (RuntimeError, _lib.AntsrlError):
                     break
                 walked += 1
+                depth = sum(x.numel() for x in spacers) / 2 ** 30
                 if self._ws.data_ptr() != own_ws.data_ptr():
                     self._make_handle(own_ws)
                 scratch_episode()
@@ -250,16 +256,24 @@ class BatchedAntsEnv:
                     self._bind_outputs(mk().zero_())
                     pairs.append((self._ws, self._out_flat))
                     times.append(measure())
-                    labels.append("ws torch / out %s (walk %d: +%.0f GiB)" % (kind, walked, sum(x.numel() for x in spacers) / 2 ** 30))
+                    labels.append("ws torch / out %s (walk %d: +%.0f GiB)" % (kind, walked, depth))
+                self._make_handle(torch_u8(n_ws))
+                scratch_episode()
+                self._bind_outputs(own_out)
+                pairs.append((self._ws, self._out_flat))
+                times.append(measure())
+                labels.append("ws torch (walk %d: +%.0f GiB) / out %s" % (walked, depth, "pieced" if self._pieced else "torch"))
             best = min(range(len(times)), key=times.__getitem__)
             if verbose:
                 print("tune_placement: ms/step per (workspace, outputs) pair %s -> %d" % (["%.4f" % t for t in times], best))
             ws, out = pairs[best]
             del pairs, spacers
-            torch.cuda.empty_cache()  # (the spacers and the losing torch buffers go back to the driver)
             if ws.data_ptr() != self._ws.data_ptr():
                 self._make_handle(ws)
             self._bind_outputs(out)
+            if walked:  # (the walk's spacers and losing buffers: torch's go back to the driver, the pool's are unmapped — their
+                vmm.trim()  # ranges retired, never re-used; without a walk the few losing buffers simply stay pooled)
+            torch.cuda.empty_cache()
             self._out_flat.zero_()
             del own_ws, own_out, ws, out
         self.placement_trials = dict(ms_per_step=[round(t, 5) for t in times], chosen=best, pairs=labels,

@@ -121,14 +121,6 @@ def test_tune_placement_leaves_a_clean_handle():
     times = a.tune_placement(age=20, steps=8, walk_spacers=0)
     assert times is not None and len(times) == 8 and a.placement_trials["chosen"] in range(8)  # (four pairs + four more draws)
     assert len(BatchedAntsEnv(cfg).tune_placement(age=10, steps=4, extra_outputs=0, walk_spacers=0)) == 4
-    # the walk (taken when every pair sat on one level): one 4 GiB spacer, two more draws; everything but the kept pair freed
-    w = BatchedAntsEnv(cfg)
-    tw = w.tune_placement(age=10, steps=4, extra_outputs=0, walk_spacers=1, spacer_gib=4.0)
-    assert len(tw) in (4, 6) and w.placement_trials["walk_steps"] == (len(tw) - 4) // 2
-    ok = [t for t in tw if t < 1.25 * min(tw)]
-    assert w.placement_trials["both_levels_seen"] == (max(ok) >= 1.06 * min(ok))
-    del w
-    assert BatchedAntsEnv(cm.make_cfg(2, 8, 32, 32)).tune_placement() is None  # (small batches: nothing to alias)
     a.reset(init)
     b.reset(init)
     from antsrl_amd import _lib
@@ -143,3 +135,23 @@ def test_tune_placement_leaves_a_clean_handle():
         assert (x == y).all()
     for which in (cm.S_ANTS_XYT, cm.S_PHERO, cm.S_FOOD, cm.S_EXPLORED, cm.S_TIMESTEP):
         assert torch.equal(a.read_state(which), b.read_state(which))
+    # the walk (taken when every pair sat on one level; forced here): per step a 4 GiB spacer from each allocator, two more
+    # output buffers and one more workspace; the kept pair steps like any other env, everything else goes back to the device
+    del a, ha, hb
+    gc.collect()
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    w = BatchedAntsEnv(cfg)
+    tw = w.tune_placement(age=10, steps=4, extra_outputs=0, walk_spacers=2, spacer_gib=4.0, force_walk=True)
+    assert len(tw) == 4 + 2 * 3 and w.placement_trials["walk_steps"] == 2
+    ok = [t for t in tw if t < 1.25 * min(tw)]
+    assert w.placement_trials["both_levels_seen"] == (max(ok) >= 1.06 * min(ok))
+    w.reset(init)
+    b.reset(init)
+    for t in range(3):
+        for x, y in zip(w.step_update(rot[t], ph[t], None), b.step_update(rot[t], ph[t], None)):
+            assert torch.equal(x, y)
+    del w
+    gc.collect()
+    torch.cuda.synchronize()
+    assert free0 - torch.cuda.mem_get_info()[0] < (3 << 30), "the walk's spacers were not returned to the device"
