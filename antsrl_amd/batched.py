@@ -43,6 +43,14 @@ def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
+def placement_levels_seen(times) -> bool:
+    """tune_placement's stopping rule: have the trials shown BOTH placement levels (15 % apart at c3)?
+    A spread of 6 % or more among the trials — not counting a trial far above everything else, which is not a level (a
+    first touch, a profiler's hiccup: 0.32 ms among 0.233s on a device whose every buffer sat on the slow level)."""
+    ok = [t for t in times if t < 1.25 * min(times)]
+    return max(ok) >= 1.06 * min(ok)
+
+
 class BatchedAntsEnv:
     def __init__(self, cfg: AntsCfg, device: Optional[torch.device] = None, obs_dtype: torch.dtype = torch.float32,
                  obs_row_stride=None, pieced_memory: bool = True):
@@ -229,11 +237,7 @@ class BatchedAntsEnv:
             # Both levels seen?  If not, walk further into the device's memory until a buffer of another zone turns up.
             spacers = []
             walked = 0
-            def both_levels(ts):
-                # (a trial far above everything else — a first touch, a profiler's hiccup — is not a level: 0.32 ms among
-                #  0.233s on a device whose every buffer sat on the slow level, under rocprofv3)
-                ok = [t for t in ts if t < 1.25 * min(ts)]
-                return max(ok) >= 1.06 * min(ok)
+            both_levels = placement_levels_seen
             while self._pieced and walked < int(walk_spacers) and (force_walk or not both_levels(times)):
                 # one step of the walk: a spacer from EACH allocator (hipMalloc and the virtual-memory one draw from
                 # different ends of the device's memory: profiles/r05/two_colour.txt), then one more output buffer of each

@@ -35,12 +35,17 @@ def hipcc() -> str:
     raise RuntimeError("hipcc not found (needs the ROCm toolchain)")
 
 
+#: host-only translation units (no kernel in them): a change there moves no byte on the device
+HOST_ONLY_SOURCES = ("antsrl_capi.hip", "antsrl_mem.hip")
+
+
 def source_hash() -> str:
-    """sha256 (first 16 hex digits) over the kernel sources and the C-ABI header: what a measurement was taken ON
-    (profiles/traffic_<config>.json records it; bench.py flags PMC figures that pre-date the tree it runs)."""
+    """sha256 (first 16 hex digits) over the KERNEL sources (every translation unit with device code + the shared headers +
+    the C-ABI header): what a measurement was taken ON (profiles/traffic_<config>.json records it; bench.py flags PMC
+    figures that pre-date the kernels it runs)."""
     import hashlib
     h = hashlib.sha256()
-    for path in sorted([os.path.join(CSRC, s) for s in SOURCES] + [os.path.normpath(x) for x in HEADERS]):
+    for path in sorted([os.path.join(CSRC, s) for s in SOURCES if s not in HOST_ONLY_SOURCES] + [os.path.normpath(x) for x in HEADERS]):
         h.update(os.path.basename(path).encode())
         h.update(open(path, "rb").read())
     return h.hexdigest()[:16]

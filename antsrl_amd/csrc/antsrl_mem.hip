@@ -2,15 +2,14 @@
 // from physical PIECES of at most ANTSRL_MEM_PIECE_BYTES mapped into one virtual range (HIP virtual-memory management).
 //
 // Why the library offers an allocator at all (it never allocates inside a step): on MI355X the same kernels on the same
-// inputs run 15 % apart depending on the PHYSICAL layout of the two big buffers — the observation tensor (a 0.7 GB write
-// stream of 1372-byte rows, 702 464 bytes from one environment to the next) and the workspace's cell records (the
-// gathers).  When both lie in physically contiguous ranges of 128 MiB or more — what hipMalloc hands a fresh process —
-// the streams alias on the memory channels: k_perceive 0.197 ms at c3.  With the observation tensor in pieces of <= 32 MiB
-// it is 0.167-0.174 ms on nearly every allocation (profiles/history/r04/placement_probe4*.txt: pieces of 2 / 8 / 32 MiB fast,
-// 128 / 256 / 512 / 1024 MiB slow; hipExtMallocWithFlags' fully contiguous memory was 25 % slower still,
-// profiles/r03/box_state_probe3.txt).  Not a law: BOTH buffers pieced was slower again, and some processes' first
-// allocations stay slow either way, which is why the host side measures (BatchedAntsEnv.tune_placement,
-// profiles/r04/ROUND_NOTES.md).  Offsets INSIDE an allocation change nothing (placement_probe.txt).
+// inputs run 15 % apart depending on WHERE the two big buffers lie — the observation tensor (a 0.7 GB streaming write) and
+// the workspace's cell records (scattered gathers).  The device's memory falls into a few large zones, and k_perceive is
+// slow (0.197 against 0.167 ms at c3) exactly when the two lie in the same one (profiles/r05/two_colour.txt, region_map.txt;
+// DESIGN.md section 2).  In a fresh process hipMalloc and the virtual-memory allocator used here draw from DIFFERENT zones, so
+// a workspace from hipMalloc / torch.empty and an observation tensor from antsrl_mem_alloc are a fast pair, two hipMalloc
+// buffers the slow one — until tens of GB are in use and either allocator has wandered into the other's zone, which is why
+// the host side measures (BatchedAntsEnv.tune_placement).  Offsets inside an allocation and the stream's pitches change
+// nothing (profiles/history/r04/placement_probe.txt, profiles/r05/env_pitch_probe.txt).
 // Freed blocks are POOLED, not unmapped (round 5): antsrl_mem_free parks the block — range and pieces, still mapped — on a
 // per-device free list keyed by its size, antsrl_mem_alloc hands a parked block of the same device and size back before it
 // creates anything.  No hipMemUnmap on any path a running program takes, so no address is ever translated to anything but

@@ -1,11 +1,12 @@
 """torch tensors over antsrl_mem_alloc (include/antsrl.h): device memory in physical pieces of at most 16 MiB.
 
-On MI355X the physical layout of the step's two big buffers — the workspace's cell records and the observation tensor —
-is worth 15 % of the observation kernel: hipMalloc (what torch.empty ends in) hands a fresh process physically contiguous
-ranges of hundreds of MiB, on which the observation write stream and the record gathers alias on the memory channels
-(k_perceive 0.197 ms at c3); with the observation tensor in pieces of <= 32 MiB it takes 0.167-0.174 ms on nearly every
-allocation (profiles/history/r04/placement_probe4*.txt; BatchedAntsEnv.tune_placement measures the box at hand).  `pieced_u8(nbytes, device)` is a uint8 tensor over such memory.  PyTorch stays
-plumbing: the tensor wraps the pointer through `__cuda_array_interface__`."""
+On MI355X the observation kernel runs 15 % slower when the observation tensor (a streaming write) and the workspace's cell
+records (scattered gathers) lie in the same ZONE of the device's memory (profiles/r05/two_colour.txt).  In a
+fresh process hipMalloc (what torch.empty ends in) and the HIP virtual-memory allocator draw from different zones: the
+observation tensor on antsrl_mem_alloc pieces + the workspace on torch.empty is a fast pair (k_perceive 0.167 against 0.197 ms
+at c3), two torch.empty buffers the slow one; BatchedAntsEnv.tune_placement measures the device at hand.
+`pieced_u8(nbytes, device)` is a uint8 tensor over such memory.  PyTorch stays plumbing: the tensor wraps the pointer through
+`__cuda_array_interface__`."""
 from __future__ import annotations
 
 import ctypes as C

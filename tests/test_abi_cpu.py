@@ -165,3 +165,16 @@ def test_batched_env_fails_loudly_without_gpu():
     from antsrl_amd.batched import BatchedAntsEnv
     with pytest.raises(_lib.AntsrlError):
         BatchedAntsEnv(make_cfg(1, 4, 16, 16))
+
+
+def test_placement_tuner_stopping_rule():
+    """BatchedAntsEnv.tune_placement walks further into the device's memory until its trials have shown both placement levels
+    (profiles/r05/two_colour.txt): the rule on recorded trial sets."""
+    from antsrl_amd.batched import placement_levels_seen
+    fresh = [0.20761, 0.23375, 0.22291, 0.23091, 0.2008, 0.20152, 0.20208, 0.20301]      # a fresh process on a fast device
+    one_level = [0.23279, 0.23461, 0.23397, 0.23541, 0.23309, 0.23433, 0.23434, 0.23468]  # device 0xb6d3a6e8...: every trial slow
+    assert placement_levels_seen(fresh)
+    assert not placement_levels_seen(one_level)
+    assert not placement_levels_seen(one_level + [0.32247])          # an outlier is not a level
+    assert placement_levels_seen(one_level + [0.32247, 0.2012])      # ... a buffer of another zone is
+    assert not placement_levels_seen([0.0358, 0.0352, 0.0357, 0.0351])  # c2: no zone effect at all
