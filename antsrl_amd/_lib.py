@@ -92,3 +92,26 @@ def check(rc: int, what: str = "antsrl") -> None:
     if rc != 0:
         msg = load().antsrl_last_error().decode("utf-8", "replace")
         raise AntsrlError("%s failed (%d): %s" % (what, rc, msg))
+
+
+class HipEvents:
+    """Raw hipEvent_t handles (the ABI hook records them on the launch stream)."""
+
+    def __init__(self, n):
+        self.hip = hip_runtime()  # the runtime torch already loaded, not a second copy
+        self.ev = []
+        for _ in range(n):
+            e = C.c_void_p()
+            rc = self.hip.hipEventCreate(C.byref(e))
+            assert rc == 0, "hipEventCreate failed: %d" % rc
+            self.ev.append(e)
+
+    def elapsed_ms(self, a, b):
+        ms = C.c_float()
+        rc = self.hip.hipEventElapsedTime(C.byref(ms), self.ev[a], self.ev[b])
+        assert rc == 0, "hipEventElapsedTime failed: %d" % rc
+        return ms.value
+
+    def destroy(self):
+        for e in self.ev:
+            self.hip.hipEventDestroy(e)

@@ -79,28 +79,7 @@ def algorithmic_bytes(N, W, H, Cn, K, P=49, obs_bytes=4):
                 total=sweep + move + perceive + update)
 
 
-class HipEvents:
-    """Raw hipEvent_t handles (the ABI hook records them on the launch stream)."""
-
-    def __init__(self, n):
-        from antsrl_amd._lib import hip_runtime
-        self.hip = hip_runtime()  # the runtime torch already loaded, not a second copy
-        self.ev = []
-        for _ in range(n):
-            e = C.c_void_p()
-            rc = self.hip.hipEventCreate(C.byref(e))
-            assert rc == 0, "hipEventCreate failed: %d" % rc
-            self.ev.append(e)
-
-    def elapsed_ms(self, a, b):
-        ms = C.c_float()
-        rc = self.hip.hipEventElapsedTime(C.byref(ms), self.ev[a], self.ev[b])
-        assert rc == 0, "hipEventElapsedTime failed: %d" % rc
-        return ms.value
-
-    def destroy(self):
-        for e in self.ev:
-            self.hip.hipEventDestroy(e)
+from antsrl_amd._lib import HipEvents  # noqa: E402  (raw hipEvent_t handles: the ABI's timing hook records them on the launch stream)
 
 
 def device_identity(torch, index):
