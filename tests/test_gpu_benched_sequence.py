@@ -129,6 +129,59 @@ def test_benched_random_policy_loop_vs_oracle(name, E, N, rocks, age):
     assert sum(float((o.holding > 0).sum()) for o in orcs) > 0
 
 
+def test_benched_sequence_with_the_reference_drivers_reward():
+    """main.py:42 does not run ExplorationReward but All_Rewards(fct_explore=1, fct_food=2, fct_anthill=10,
+    fct_explore_holding=1, fct_headinganthill=3), with reward_threshold 1 (main.py:44): the full c3 batch through the benched
+    call sequence with THAT reward (k_perceive's epilogue then reads previous holding / previous distance and writes them
+    back, and the tint is set from the weighted sum), 300 steps, five sampled environments against the oracle — reward
+    bit-exact at every step (on these inputs no ant sits on a mathematical tie of the heading term: test_gpu_parity's
+    _check_reward documents that one exception), reward_state (the viewer's tint, ants.py:119-130) and the rest of the state
+    exact at the end."""
+    import torch
+    from antsrl_amd import config as cm
+    from antsrl_amd.batched import BatchedAntsEnv
+    from antsrl_amd.synth import synth_init
+    from oracle.oracle import Oracle
+    E, N, W, H, rocks, steps = 1024, 512, 256, 256, 8, 300
+    rank, world = 2, 8
+    base = rank * E
+    kw = dict(n_rocks=rocks, deposit_strength=256.0, max_time=1 << 30, reward_kind=cm.REWARD_ALL, reward_threshold=1.0,
+              fct_explore=1.0, fct_food=2.0, fct_anthill=10.0, fct_explore_holding=1.0, fct_headinganthill=3.0)
+    cfg = cm.make_cfg(E, N, W, H, env_id_base=base, n_envs_total=world * E, **kw)
+    init = synth_init(cfg, seed=1234, env_offset=base)
+    env = BatchedAntsEnv(cfg)
+    env.reset(init)
+    if not (env.query(cm.Q_INTERLEAVED) == 1 and env.query(cm.Q_DEFERRED_UPDATE) == 1):
+        pytest.skip("a profiling switch took the handle off the benched path (tests/alt_paths.sh)")
+    dev = env.device
+    g = torch.Generator(device=dev)
+    g.manual_seed(99 + rank)
+    rot = torch.randint(-1, 2, (RING, E, N), generator=g, device=dev, dtype=torch.int8)
+    ph = torch.randint(0, 3, (RING, E, N), generator=g, device=dev, dtype=torch.int8)
+    pick = [0, 1, E // 2 - 1, E - 2, E - 1]
+    pidx = torch.tensor(pick, device=dev)
+    rew_log = torch.empty((steps, len(pick), N), dtype=torch.float32, device=dev)
+    for t in range(steps):
+        obs, ast, rew, done = env.step_update(rot[t % RING], ph[t % RING], None)
+        rew_log[t] = rew[pidx]
+    torch.cuda.synchronize(dev)
+    rot_h, ph_h, rew_h = rot[:, pidx].cpu().numpy(), ph[:, pidx].cpu().numpy(), rew_log.cpu().numpy()
+    orcs = _oracles(cm, Oracle, kw, N, W, H, init, pick, base)
+    seen = set()
+    for t in range(steps):
+        for j, o in enumerate(orcs):
+            _, _, o_rew, _ = o.step(rot_h[t % RING, j:j + 1], ph_h[t % RING, j:j + 1], want_obs=False)
+            o.update(None)
+            np.testing.assert_array_equal(rew_h[t, j], o_rew[0].astype(np.float32), err_msg="All_Rewards, step %d env %d" % (t, pick[j]))
+            seen.update(np.unique(np.round(o_rew[0], 6)).tolist())
+    # every term of the sum has fired somewhere: exploration (multiples of 0.1), food (2 per unit picked up), anthill (10)
+    assert any(abs(v - 10.0) < 1e-6 or v > 10.0 for v in seen) and any(1.9 < v < 10.0 for v in seen) and any(0 < v < 1.9 for v in seen), sorted(seen)[-8:]
+    _final_state_checks(cm, env, orcs, pick, rocks)
+    rs = env.read_state(cm.S_REWARD_STATE).cpu().numpy()
+    for j, g_ in enumerate(pick):
+        np.testing.assert_array_equal(rs[g_], orcs[j].reward_state[0], err_msg="reward_state (tint), env %d" % g_)
+
+
 def test_full_reference_episode_2000_steps_c3():
     """The reference's episode is 2000 steps (main.py:31): the full BASELINE configs[2] batch run that long through the
     benched call sequence, five sampled environments replayed by the oracle — reward bit-exact at EVERY step, and every 100
