@@ -467,6 +467,15 @@ class BatchedAntsEnv:
         with self._on_device():
             _lib.check(self.lib.antsrl_update(self._h, _ptr(j), self._stream()), "update")
 
+    def update_phase(self, phase: int, wall_jitter=None) -> None:
+        """antsrl_update_phase: one of the four reference steps of Environment.update (config.PHASE_WALLS,
+        PHASE_ROCKS_PHEROMONE, PHASE_ANTS, PHASE_ANTHILL, in this order) — for callers whose own EnvObjects run between
+        the world's objects (rl_api.Environment.update does that)."""
+        c = self.cfg
+        j = self._dev(wall_jitter, torch.float64, (c.n_envs, c.n_ants)) if phase == cfgmod.PHASE_WALLS else None
+        with self._on_device():
+            _lib.check(self.lib.antsrl_update_phase(self._h, int(phase), _ptr(j), self._stream()), "update_phase")
+
     def flush(self) -> None:
         """antsrl_flush: enqueue a deferred Environment.update now (before copying / checkpointing the workspace, or
         to time the update on its own); a no-op when nothing is pending."""

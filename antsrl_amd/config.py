@@ -108,6 +108,8 @@ class AntsGen(C.Structure):
 
 
 WALLS_BERNOULLI, WALLS_PERLIN, WALLS_INPUT = 0, 1, 2
+#: antsrl_update_phase (include/antsrl.h): the reference's update steps -1 / 0 / 999 / 1000
+PHASE_WALLS, PHASE_ROCKS_PHEROMONE, PHASE_ANTS, PHASE_ANTHILL = 0, 1, 2, 3
 RNG_COUNTER, RNG_REFERENCE = 0, 1
 
 

@@ -20,13 +20,13 @@ hipError_t antsrl_launch_act(const KP &p, const int8_t *rot, const int8_t *ph, i
 bool antsrl_act_fits(const KP &p);
 bool antsrl_act_needs_hbm_maps(const KP &p);
 hipError_t antsrl_launch_sweep(const KP &p, int cur, hipStream_t st);
-hipError_t antsrl_launch_update(const KP &p, const double *jitter, int out_buf, hipStream_t st);
+hipError_t antsrl_launch_update(const KP &p, const double *jitter, int out_buf, hipStream_t st, int phases = 15);
 hipError_t antsrl_launch_collect_full(const KP &p, hipStream_t st);
 hipError_t antsrl_launch_reset(const KP &p, const AntsInit *in, hipStream_t st);
 hipError_t antsrl_launch_set_activation(const KP &p, const float *act, hipStream_t st);
 hipError_t antsrl_launch_read_state(const KP &p, int which, int cur, void *dst, hipStream_t st);
 hipError_t antsrl_launch_generate(const KP &p, const AntsGen &g, uint64_t seed, hipStream_t st);
-hipError_t antsrl_launch_phero_wall_clear(const KP &p, hipStream_t st);
+hipError_t antsrl_launch_phero_wall_clear(const KP &p, hipStream_t st, int buf = 0);
 hipError_t antsrl_launch_phero_renorm(const KP &p, hipStream_t st);
 // cell-meta path (antsrl_perceive.hip)
 bool antsrl_meta_supported(const KP &p);
@@ -71,6 +71,7 @@ struct AntsHandle {
     bool pend_update;
     KP pend_p;             // kernel parameters as they stood at the update's call (g_dep / inv_g_dep differ afterwards)
     int pend_out_buf;
+    int phase_next;        // antsrl_update_phase: the next phase of an Environment.update in progress (0: none in progress)
 };
 
 static thread_local char g_err[512] = "";
@@ -343,6 +344,7 @@ extern "C" int antsrl_create(const AntsCfg *cfg, void *workspace, size_t workspa
     fill_kp(cfg, &h->p);
     carve(cfg, &h->p.s, (unsigned char *)workspace);
     h->cur = 0; h->steps_since_update = 0; h->need_full_collect = true; h->is_reset = false; h->episode_over = false; h->pend_update = false;
+    h->phase_next = 0;
     h->pol = PolArgs{};
     h->sweeps = 0; h->need_wall_clear = false;
     h->has_gen = false; h->episode_seed = 0; h->host_timestep = 1; h->obs_bf16 = false; h->obs_pitch = 0;
@@ -381,6 +383,7 @@ extern "C" int antsrl_reset(AntsHandle *h, const AntsInit *init, void *stream)
         return fail(ANTSRL_E_INVALID, "AntsInit: ants_xyt, seed, walls, food, anthill_xyr are required");
     if (h->p.R > 0 && !init->rocks) return fail(ANTSRL_E_INVALID, "AntsInit.rocks is NULL but n_rocks > 0");
     h->pend_update = false; // (a deferred update of the state being replaced)
+    h->phase_next = 0;
     hipError_t e = antsrl_launch_reset(h->p, init, (hipStream_t)stream);
     if (e != hipSuccess) return hip_fail(e, "reset");
     h->p.deposit_strength = h->cfg.deposit_strength;
@@ -408,6 +411,7 @@ static int do_generate(AntsHandle *h, uint64_t seed, hipStream_t st)
     int rc = check_gen_seed(h, h->gen, seed);
     if (rc) return rc;
     h->pend_update = false; // (a deferred update of the state being replaced)
+    h->phase_next = 0;
     hipError_t e = antsrl_launch_generate(h->p, h->gen, seed, st);
     if (e != hipSuccess) return hip_fail(e, "generate");
     h->p.deposit_strength = h->cfg.deposit_strength;
@@ -506,6 +510,11 @@ static int not_reset(const AntsHandle *h)
         return fail(ANTSRL_E_INVALID, "the episode is over and its auto-reset was refused (episode seed past np.random.seed's 32 bits): "
                                       "call antsrl_reset or antsrl_generate");
     return fail(ANTSRL_E_INVALID, "antsrl_reset has not been called on this handle");
+}
+
+static int mid_update(const AntsHandle *h)
+{
+    return fail(ANTSRL_E_INVALID, "an Environment.update is in progress (antsrl_update_phase %d of 4 is next): finish it first", h->phase_next);
 }
 
 // One observation on the cell-meta path: k_move (with the action phases when `stepping`) then k_perceive.
@@ -630,6 +639,7 @@ extern "C" int antsrl_step(AntsHandle *h, const int8_t *rotation, const int8_t *
 {
     if (!h) return fail(ANTSRL_E_INVALID, "NULL handle");
     if (!h->is_reset) return not_reset(h);
+    if (h->phase_next) return mid_update(h);
     if (!agent_state || !reward || !done) return fail(ANTSRL_E_INVALID, "agent_state, reward, done are required");
     return do_step(h, rotation, phero, obs, agent_state, reward, done, (hipStream_t)stream);
 }
@@ -638,6 +648,7 @@ extern "C" int antsrl_observe(AntsHandle *h, float *obs, float *agent_state, flo
 {
     if (!h) return fail(ANTSRL_E_INVALID, "NULL handle");
     if (!h->is_reset) return not_reset(h);
+    if (h->phase_next) return mid_update(h);
     if (h->p.meta)
         return meta_observe(h, nullptr, nullptr, obs, agent_state, reward, nullptr, false, (hipStream_t)stream, false);
     if (obs && h->obs_pitch) return fail(ANTSRL_E_UNSUPPORTED, "antsrl_set_obs_row_stride needs the cell-meta path (ANTSRL_Q_CELL_META)");
@@ -653,7 +664,74 @@ extern "C" int antsrl_update(AntsHandle *h, const double *wall_jitter, void *str
 {
     if (!h) return fail(ANTSRL_E_INVALID, "NULL handle");
     if (!h->is_reset) return not_reset(h);
+    if (h->phase_next) return mid_update(h);
     return do_update(h, wall_jitter, (hipStream_t)stream, false, false, true);
+}
+
+// Environment.update one reference step at a time (include/antsrl.h).  Bit-identical to antsrl_update: the same device
+// functions in the same order, cut at the launch boundaries.
+extern "C" int antsrl_update_phase(AntsHandle *h, int phase, const double *wall_jitter, void *stream)
+{
+    if (!h) return fail(ANTSRL_E_INVALID, "NULL handle");
+    if (!h->is_reset) return not_reset(h);
+    if (phase < ANTSRL_PHASE_WALLS || phase > ANTSRL_PHASE_ANTHILL) return fail(ANTSRL_E_INVALID, "bad phase %d", phase);
+    if (phase != h->phase_next)
+        return fail(ANTSRL_E_INVALID, "antsrl_update_phase: phase %d is next, got %d (WALLS, ROCKS_PHEROMONE, ANTS, ANTHILL in order)", h->phase_next, phase);
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e;
+    if (phase == ANTSRL_PHASE_WALLS) { // walls.py:22-30 (update_step -1)
+        int frc = flush_pending(h, st);
+        if (frc) return frc;
+        if (h->p.scaled) {
+            if (h->p.g_dep < 1e-20) { // re-base the units long before u = v / f0^S can overflow fp32 (value-preserving)
+                e = antsrl_launch_phero_renorm(h->p, st);
+                if (e != hipSuccess) return hip_fail(e, "pheromone renorm");
+                h->sweeps = 0;
+                set_decay(h);
+            }
+            if (h->need_wall_clear) {
+                e = antsrl_launch_phero_wall_clear(h->p, st);
+                if (e != hipSuccess) return hip_fail(e, "pheromone wall clear");
+                h->need_wall_clear = false;
+            }
+        } else { // `phero[map] = 0` as a step of its own (the sweep of the next phase does it again, to the same effect)
+            e = antsrl_launch_phero_wall_clear(h->p, st, h->cur);
+            if (e != hipSuccess) return hip_fail(e, "pheromone wall clear");
+        }
+        e = antsrl_launch_update(h->p, wall_jitter, h->p.scaled ? 0 : h->cur, st, 1 /* UPD_WALLS */);
+        if (e != hipSuccess) return hip_fail(e, "update: walls");
+    } else if (phase == ANTSRL_PHASE_ROCKS_PHEROMONE) { // circle_obstacles.py:32-58, pheromone.py:43-45 (update_step 0)
+        e = antsrl_launch_update(h->p, nullptr, h->p.scaled ? 0 : h->cur, st, 2 /* UPD_ROCKS */);
+        if (e != hipSuccess) return hip_fail(e, "update: rocks");
+        if (h->p.scaled) { // the conceptual sweep: readers materialise one more decay from here on; the deposit of the
+            h->sweeps++;   // ANTS phase lands "after the sweep of this update" = at the new g_now
+            set_decay(h);
+        } else {
+            e = antsrl_launch_sweep(h->p, h->cur, st);
+            if (e != hipSuccess) return hip_fail(e, "pheromone sweep");
+            h->cur ^= 1; // readers (and the deposit) see the swept grid from here on
+        }
+    } else if (phase == ANTSRL_PHASE_ANTS) { // ants.py:123-130 (update_step 999)
+        KP kp = h->p;
+        if (kp.scaled) { // (the units were advanced in the previous phase: the deposit factor is the CURRENT decay)
+            kp.g_dep = kp.g_now;
+            kp.inv_g_dep = 1.0 / kp.g_dep;
+        }
+        e = antsrl_launch_update(kp, nullptr, kp.scaled ? 0 : h->cur, st, 4 /* UPD_ANTS */);
+        if (e != hipSuccess) return hip_fail(e, "update: ants");
+    } else { // anthill.py:41-46 (update_step 1000); the environment's timestep advances here
+        e = antsrl_launch_update(h->p, nullptr, h->p.scaled ? 0 : h->cur, st, 8 /* UPD_ANTHILL */);
+        if (e != hipSuccess) return hip_fail(e, "update: anthill");
+        if (h->need_full_collect) {
+            e = antsrl_launch_collect_full(h->p, st);
+            if (e != hipSuccess) return hip_fail(e, "anthill collect");
+            h->need_full_collect = false;
+        }
+        h->steps_since_update = 0;
+        h->host_timestep++;
+    }
+    h->phase_next = (phase + 1) % 4;
+    return ANTSRL_OK;
 }
 
 extern "C" int antsrl_flush(AntsHandle *h, void *stream)
@@ -668,6 +746,7 @@ extern "C" int antsrl_step_update(AntsHandle *h, const int8_t *rotation, const i
 {
     if (!h) return fail(ANTSRL_E_INVALID, "NULL handle");
     if (!h->is_reset) return not_reset(h);
+    if (h->phase_next) return mid_update(h);
     if (!agent_state || !reward || !done) return fail(ANTSRL_E_INVALID, "agent_state, reward, done are required");
     hipStream_t st = (hipStream_t)stream;
     const bool timed = h->ev_armed;
@@ -762,6 +841,7 @@ extern "C" int antsrl_set_activation(AntsHandle *h, const float *act, double new
 {
     if (!h || !act) return fail(ANTSRL_E_INVALID, "NULL handle or act");
     if (!h->is_reset) return not_reset(h);
+    if (h->phase_next) return mid_update(h);
     int frc = flush_pending(h, (hipStream_t)stream); // (the deferred update deposits with the activation as it was)
     if (frc) return frc;
     hipError_t e = antsrl_launch_set_activation(h->p, act, (hipStream_t)stream);

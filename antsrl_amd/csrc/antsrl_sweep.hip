@@ -127,13 +127,15 @@ k_sweep_tiled(const KP p, const float *__restrict__ in, float *__restrict__ out)
 
 // Scaled mode helpers (rare, full-grid): zero the wall cells of the grid (first update after a
 // reset that supplied an initial pheromone grid) and re-base the units when f0^S gets tiny.
-__global__ void __launch_bounds__(256) k_phero_wall_clear(const KP p)
+// (`buf`: the pheromone buffer — 0 with scaled units; the current one when antsrl_update_phase runs Walls.update's
+//  `phero[map] = 0`, walls.py:30, as a step of its own under an explicit sweep)
+__global__ void __launch_bounds__(256) k_phero_wall_clear(const KP p, const int buf)
 {
     const size_t G = (size_t)p.W * p.H, n = (size_t)p.E * G;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const size_t e = i / G, g = i - e * G;
         if (test_bit(p.s.walls_bits + e * p.words, (uint32_t)g))
-            for (int c = 0; c < p.C; ++c) p.s.phero[0][(e * G + prec_cell(p, (uint32_t)g)) * p.ps + c] = 0.0f;
+            for (int c = 0; c < p.C; ++c) p.s.phero[buf][(e * G + prec_cell(p, (uint32_t)g)) * p.ps + c] = 0.0f;
     }
 }
 
@@ -729,9 +731,9 @@ hipError_t antsrl_launch_sweep(const KP &p, int cur, hipStream_t st)
     }
 }
 
-hipError_t antsrl_launch_phero_wall_clear(const KP &p, hipStream_t st)
+hipError_t antsrl_launch_phero_wall_clear(const KP &p, hipStream_t st, int buf)
 {
-    hipLaunchKernelGGL(k_phero_wall_clear, dim3(grid_for((size_t)p.E * p.W * p.H)), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(k_phero_wall_clear, dim3(grid_for((size_t)p.E * p.W * p.H)), dim3(256), 0, st, p, buf);
     return hipGetLastError();
 }
 

@@ -6,10 +6,10 @@
 
 template <int C>
 __global__ void __launch_bounds__(1024)
-k_update(const KP p, const double *__restrict__ wall_jitter, const int out_buf)
+k_update(const KP p, const double *__restrict__ wall_jitter, const int out_buf, const int phases)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    update_env<C>(p, blockIdx.x, wall_jitter, out_buf, smem);
+    update_env<C>(p, blockIdx.x, wall_jitter, out_buf, smem, phases);
 }
 
 template <int C>
@@ -51,10 +51,11 @@ __global__ void __launch_bounds__(256) k_collect_full(const KP p)
 static inline int pick_update_threads(int N) { (void)N; return 512; }
 static size_t update_lds_bytes(const KP &p, int threads) { return update_scratch_bytes(p.HT, p.R, threads / 64); }
 
-hipError_t antsrl_launch_update(const KP &p, const double *jitter, int out_buf, hipStream_t st)
+// phases: UPD_ALL (one Environment.update) or a subset of its steps (antsrl_update_phase: the per-phase loop kernel runs them)
+hipError_t antsrl_launch_update(const KP &p, const double *jitter, int out_buf, hipStream_t st, int phases)
 {
     static const bool force_loops = PROF_ENV("ANTSRL_UPDATE_LOOPS") != nullptr; // A/B: the per-phase loop kernel
-    if (p.N <= 1024 && !force_loops) { // one ant per thread
+    if (p.N <= 1024 && !force_loops && phases == UPD_ALL) { // one ant per thread
         const int t1 = (p.N + 63) / 64 * 64;
         const size_t l1 = update_one_lds_bytes(p.HT, p.R, t1 / 64, p.N);
         switch (p.C) {
@@ -80,7 +81,7 @@ hipError_t antsrl_launch_update(const KP &p, const double *jitter, int out_buf, 
             if (err != hipSuccess) return err;                                                                     \
             seen[dev] = lds;                                                                                       \
         }                                                                                                          \
-        hipLaunchKernelGGL((k_update<CC>), dim3(p.E), dim3(threads), lds, st, p, jitter, out_buf);                 \
+        hipLaunchKernelGGL((k_update<CC>), dim3(p.E), dim3(threads), lds, st, p, jitter, out_buf, phases);         \
     }
     switch (p.C) {
     case 1: UPDATE_GO(1) break;

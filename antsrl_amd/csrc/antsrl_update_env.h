@@ -29,9 +29,20 @@ __device__ __forceinline__ uint32_t block_excl_scan_flag(bool flag, uint32_t *wa
 
 // The update phases of ONE environment, run by the whole workgroup.  `smem` is
 // update_scratch_bytes() of LDS.  Called by k_update and, fused, at the tail of k_act.
+// `phases` (UPD_*): which of the reference's update steps this call runs — Walls.update (step -1), CircleObstacles.update
+// (0), Ants.update (999), Anthill.update (1000); all of them = one Environment.update.  antsrl_update_phase
+// (include/antsrl.h) enqueues them one launch at a time so that HOST EnvObjects of the caller can run between them in
+// update_step() order (environment.py:43-47); the pheromone's own step-0 update is the host's sweep launch / scaled-unit
+// bookkeeping.  The environment's timestep advances with the LAST phase (the jitter of the first one is keyed on
+// timestep + 1 either way).
+#define UPD_WALLS 1
+#define UPD_ROCKS 2
+#define UPD_ANTS 4
+#define UPD_ANTHILL 8
+#define UPD_ALL 15
 template <int C>
 __device__ __forceinline__ void update_env(const KP &p, const int e, const double *__restrict__ wall_jitter,
-                                           const int out_buf, unsigned char *smem)
+                                           const int out_buf, unsigned char *smem, const int phases = UPD_ALL)
 {
     const int tid = threadIdx.x, T = blockDim.x;
     const int lane = tid & 63, wave = tid >> 6, nwaves = T >> 6;
@@ -55,7 +66,18 @@ __device__ __forceinline__ void update_env(const KP &p, const int e, const doubl
 
     // ---- Walls.update, walls.py:25-28
     uint32_t carry = 0;
-    for (int base = 0; base < N; base += T) {
+    if (p.scaled && (phases & UPD_WALLS)) {
+        // A deposit that landed on a WALL cell in the previous update is visible to exactly one observation and is zeroed by
+        // this update's Walls pass (walls.py:30), before this update's deposits (several barriers further down).
+        for (int i = tid; i < N; i += T) {
+            const int32_t wc = p.s.walldep_cell[eN + i];
+            if (wc >= 0) {
+                for (int c = 0; c < C; ++c) out[(size_t)wc * PS + c] = 0.0f;
+                p.s.walldep_cell[eN + i] = -1;
+            }
+        }
+    }
+    for (int base = 0; (phases & UPD_WALLS) && base < N; base += T) {
         const int i = base + tid;
         bool hit = false;
         if (i < N) hit = test_bit(walls, (uint32_t)((int)p.s.x[eN + i] * H + (int)p.s.y[eN + i]));
@@ -77,7 +99,7 @@ __device__ __forceinline__ void update_env(const KP &p, const int e, const doubl
     __syncthreads();
 
     // ---- CircleObstacles.update, circle_obstacles.py:35-58
-    if (R > 0) {
+    if (R > 0 && (phases & UPD_ROCKS)) {
         // pass 1: centres -= sum_over_ants(push)/weight.  numpy sums the ants sequentially in
         // index order; non-colliding ants contribute exact zeros, so adding only the
         // colliding ones in index order reproduces the float64 result bit for bit.
@@ -144,7 +166,7 @@ __device__ __forceinline__ void update_env(const KP &p, const int e, const doubl
     }
 
     // ---- Ants.update, ants.py:123-130: prev := cur; deposit (pheromone.py:36-41)
-    for (int i = tid; i < N; i += T) {
+    for (int i = tid; (phases & UPD_ANTS) && i < N; i += T) {
         const double x = p.s.x[eN + i], y = p.s.y[eN + i];
         p.s.prev_x[eN + i] = x;
         p.s.prev_y[eN + i] = y;
@@ -152,20 +174,7 @@ __device__ __forceinline__ void update_env(const KP &p, const int e, const doubl
         p.s.reward_state[eN + i] = (uint8_t)((double)p.s.reward_state[eN + i] * 0.9); // :130
     }
     __syncthreads();
-    if (p.scaled) {
-        // A deposit that landed on a WALL cell in the previous update is visible to exactly one
-        // observation and is zeroed by this update's Walls pass (walls.py:30): clear it now.
-        for (int i = tid; i < N; i += T) {
-            const int32_t wc = p.s.walldep_cell[eN + i];
-            if (wc >= 0) {
-                for (int c = 0; c < C; ++c) out[(size_t)wc * PS + c] = 0.0f;
-                p.s.walldep_cell[eN + i] = -1;
-            }
-        }
-        __syncthreads();
-    }
-    double gain = 0.0;
-    for (int i = tid; i < N; i += T) {
+    for (int i = tid; (phases & UPD_ANTS) && i < N; i += T) {
         const uint32_t cell_id = (uint32_t)((int)p.s.x[eN + i] * H + (int)p.s.y[eN + i]); // row-major id: the wall bit map
         const uint32_t cell = prec_xy(p, (int)p.s.x[eN + i], (int)p.s.y[eN + i]);           // the cell's pheromone record
         if (lww_winner(hkeys, hvals, (uint32_t)p.HT - 1, cell) == (uint32_t)i) {
@@ -201,8 +210,11 @@ __device__ __forceinline__ void update_env(const KP &p, const int e, const doubl
                 if (on_wall && wrote) p.s.walldep_cell[eN + i] = (int32_t)cell;
             }
         }
-        // ---- Anthill.update (anthill.py:41-46), sparse: after the first full collect the only
-        // non-zero food on the area is what this step's exchange winners wrote there.
+    }
+    // ---- Anthill.update (anthill.py:41-46), sparse: after the first full collect the only
+    // non-zero food on the area is what this step's exchange winners wrote there.
+    double gain = 0.0;
+    for (int i = tid; (phases & UPD_ANTHILL) && i < N; i += T) {
         const int32_t dc = p.s.dirty_cell[eN + i];
         if (dc >= 0) {
             gain += (double)food[dc];
@@ -214,7 +226,7 @@ __device__ __forceinline__ void update_env(const KP &p, const int e, const doubl
     for (int o = 32; o > 0; o >>= 1) gain += __shfl_down(gain, o);
     if (lane == 0) red[wave] = gain;
     __syncthreads();
-    if (tid == 0) {
+    if (tid == 0 && (phases & UPD_ANTHILL)) {
         double s = 0.0;
         for (int w = 0; w < nwaves; ++w) s += red[w];
         if (s != 0.0) p.s.anthill_food[e] += s;

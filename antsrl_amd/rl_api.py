@@ -77,32 +77,40 @@ class Environment:  # environment/environment.py:21-47
         Walls.update (walls.py:28); default is the library's counter-based generator.
 
         Objects the CALLER added (any other `EnvObject` with an `update()`) are host objects: they are called like
-        the reference calls them — stable sort on `update_step()` (environment.py:43-47) — those with a negative
-        step before the device update (where Walls, step -1, runs), the others after it.  (The reference interleaves
-        by step value between its own objects' updates; a host object cannot run between two phases of one kernel,
-        so a step of 0 .. 999 runs after Anthill's 1000 here.  A host object that reads state through the views sees
-        the finished update: reads flush a deferred update first.)"""
+        the reference calls them — stable sort on `update_step()` (environment.py:43-47), BETWEEN the world's objects where
+        their step puts them: the device update is then run one reference step at a time (antsrl_update_phase: Walls -1,
+        Rocks / Pheromone 0, Ants 999, Anthill 1000) and a host object with step s runs before Walls (s < -1), after Walls
+        (-1 <= s < 0), after the rocks and the pheromone update (0 <= s < 999), after the ants' (999 <= s < 1000) or after
+        the anthill's (s >= 1000) — an object appended after the generator's keeps its place behind the world's objects
+        of equal step, as list.sort(key=update_step) leaves it.  A host object that reads state through the views sees
+        what the reference's would: the phases before it applied, the ones after it not yet.  Without such objects the
+        update is ONE call (and may be deferred into the next step's launch)."""
         host = [(o.update_step(), i, o) for i, o in enumerate(self.objects) if not _device_updates(o)]
         host.sort(key=lambda t: (t[0], t[1]))  # stable in insertion order, like list.sort(key=update_step)
-        if any(-1 <= step <= 1000 for step, _, _ in host) and not getattr(self, "_warned_interleave", False):
-            import warnings
-            warnings.warn("a host EnvObject with update_step() between -1 and 1000 runs BEFORE (negative step) or AFTER the "
-                          "whole device update here; the reference interleaves it with Walls (-1) / Rocks, Pheromone (0) / Ants "
-                          "(999) / Anthill (1000) by step and insertion order (environment.py:43-47)")
-            self._warned_interleave = True
-        # (environment.py:45 increments timestep BEFORE any object's update: a host object called in front of the device update
-        #  sees the new value)
+        b = self._backend
+
+        def run(lo, hi):
+            for step, _, o in host:
+                if lo <= step < hi:
+                    o.update()
+        # (environment.py:45 increments timestep BEFORE any object's update: a host object called while the device update
+        #  is outstanding sees the new value; the device counter advances with the last phase)
         self._host_ts_ahead = 1
         try:
-            for step, _, o in host:
-                if step < 0:
-                    o.update()
+            run(float("-inf"), -1)
+            if any(-1 <= step < 1000 for step, _, _ in host):
+                b.update_phase(cm.PHASE_WALLS, wall_jitter)
+                run(-1, 0)
+                b.update_phase(cm.PHASE_ROCKS_PHEROMONE)
+                run(0, 999)
+                b.update_phase(cm.PHASE_ANTS)
+                run(999, 1000)
+                b.update_phase(cm.PHASE_ANTHILL)
+            else:
+                b.update(wall_jitter)
         finally:
             self._host_ts_ahead = 0
-        self._backend.update(wall_jitter)
-        for step, _, o in host:
-            if step >= 0:
-                o.update()
+        run(1000, float("inf"))
 
     def save_state(self):
         """Environment.save_state (environment.py:36-40): a host snapshot for the visualiser, in the

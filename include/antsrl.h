@@ -322,6 +322,19 @@ int antsrl_observe(AntsHandle *h, float *obs, float *agent_state, float *reward,
  * antsrl_flush first. */
 int antsrl_update(AntsHandle *h, const double *wall_jitter, void *stream);
 
+/* Environment.update (environment/environment.py:42-47) ONE REFERENCE STEP AT A TIME, for callers whose own EnvObjects must
+ * run BETWEEN the world's objects: the reference sorts every object of the environment by update_step() (stable) and calls
+ * them in turn — Walls (-1), Food / CircleObstacles / Pheromone / RLApi (0), Ants (999), Anthill (1000); an object the
+ * caller added with, say, update_step() == 500 runs after the rocks and the pheromone update and before the ants'.
+ * antsrl_update_phase runs one of the four device steps and returns; the four calls in order are one antsrl_update, bit for
+ * bit (same device functions, cut at launch boundaries; never deferred).  antsrl_read_state between two phases sees the
+ * state as the reference's object would (positions already reverted off walls after WALLS, the decayed / diffused grid
+ * after ROCKS_PHEROMONE, ...).  `wall_jitter` as for antsrl_update; only WALLS reads it.  Environment.timestep advances
+ * with ANTHILL (the reference increments it before the first object: a binding that exposes `timestep` adds one while an
+ * update is in progress).  While phases are outstanding every entry point that changes the state returns ANTSRL_E_INVALID. */
+enum { ANTSRL_PHASE_WALLS = 0, ANTSRL_PHASE_ROCKS_PHEROMONE = 1, ANTSRL_PHASE_ANTS = 2, ANTSRL_PHASE_ANTHILL = 3 };
+int antsrl_update_phase(AntsHandle *h, int phase, const double *wall_jitter, void *stream);
+
 /* Enqueues a deferred update's kernel on `stream` now (no-op when none is pending): afterwards every kernel the
  * handle owes has been enqueued and, once `stream` has drained, the workspace holds the complete state.  No reference
  * counterpart (the reference updates eagerly; this is the price of k_update_move).  antsrl_destroy drops a pending

@@ -205,9 +205,9 @@ def test_host_views_read_only_what_they_show():
 
 
 def test_caller_added_env_objects_are_updated_in_update_step_order():
-    """environment.py:42-47: Environment.update calls every object's update() in stable update_step() order.  The
-    device-backed objects are one kernel; host objects the caller added run around it — negative steps before (where
-    Walls, -1, runs), the others after — each group in stable sorted order, and they see the finished update."""
+    """environment.py:42-47: Environment.update calls every object's update() in stable update_step() order.  Host objects
+    the caller added run where their step puts them among the world's objects (tests/test_gpu_update_phases.py), each
+    group in stable sorted order."""
     from antsrl_amd.rl_api import EnvObject
     api, env, F, meta = build("s02_walls")
     calls = []
@@ -248,9 +248,10 @@ def test_caller_added_env_objects_are_updated_in_update_step_order():
     assert len(snap.objects) == len(env2.save_state().objects)
 
 
-def test_overridden_view_update_is_called_and_interleaved_steps_warn():
+def test_overridden_view_update_is_called_between_the_phases():
     """a caller's subclass of a device view with its OWN update() is a host object (its update() is called); a
-    plain view is not (the kernels update it); a host object whose step falls between the device phases warns once."""
+    plain view is not (the kernels update it); a host object whose step falls between the world's objects runs between the
+    device update's phases (round 5: antsrl_update_phase; tests/test_gpu_update_phases.py pins WHAT it sees there)."""
     import warnings
     from antsrl_amd.rl_api import EnvObject, Walls
     api, env, F, meta = build("s02_walls")
@@ -276,8 +277,8 @@ def test_overridden_view_update_is_called_and_interleaved_steps_warn():
         warnings.simplefilter("always")
         env.update()
         env.update()
-    assert calls == ["moving_walls", "mid", "moving_walls", "mid"]  # Walls.update_step() is -1: in front of the device update
-    assert sum("update_step() between" in str(x.message) for x in w) == 1  # once per Environment
+    assert calls == ["moving_walls", "mid", "moving_walls", "mid"]  # Walls.update_step() is -1: right behind the world's Walls
+    assert not [x for x in w if "update_step()" in str(x.message)]  # (no "cannot interleave" warning any more)
 
 
 def test_action_arrays_must_be_whole_numbers_in_int8_range():

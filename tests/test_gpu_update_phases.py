@@ -1,0 +1,136 @@
+"""Environment.update one reference step at a time (antsrl_update_phase, include/antsrl.h): the reference calls every object of
+the environment in stable update_step() order (environment/environment.py:42-47), so an EnvObject the CALLER adds runs
+BETWEEN the world's objects — after Walls (-1), after CircleObstacles / Pheromone (0), after Ants (999), after Anthill
+(1000).  Until round 5 the device update was one kernel and such objects ran before or after all of it ("what's
+missing" #2).
+
+  * the four phases in order ARE one antsrl_update: every state array bit for bit, scaled units and explicit sweeps, with
+    rocks, library and injected jitter; out-of-order calls and state changes in the middle of an update are refused;
+  * tests/golden/contract/update_phases_ref.npz (tests/golden/make_phase_golden.py: the reference itself with six recording
+    probes at update_step -2, -1, 0, 500, 999, 1000): the shim's host objects see, at their own update(), what the
+    reference's saw."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import GOLDEN, assert_xy_close, phero_close
+
+pytestmark = pytest.mark.gpu
+
+STATE = ("S_ANTS_XYT", "S_PREV_XY", "S_HOLDING", "S_MANDIBLES", "S_ACTIVATION", "S_PHERO", "S_FOOD", "S_EXPLORED", "S_ANTHILL_FOOD",
+         "S_ROCK_CENTERS", "S_TIMESTEP", "S_REWARD_STATE")
+
+
+def _filters():
+    f3 = np.ones((3, 3)) * 0.05
+    f3[1, 1] = 1 - 8 * 0.05
+    ax = np.arange(-3, 4)
+    g = np.exp(-(ax[:, None] ** 2 + ax[None, :] ** 2) / 4.5)
+    return {"scaled": None, "diffuse3x3": f3 * (1 - 0.001), "radius3": g / g.sum() * (1 - 0.001)}
+
+
+@pytest.mark.parametrize("mode", ["scaled", "diffuse3x3", "radius3"])
+@pytest.mark.parametrize("inject", [False, True], ids=["library_jitter", "injected_jitter"])
+def test_four_phases_are_one_update(mode, inject):
+    import torch
+    from antsrl_amd import _lib, config as cm
+    from antsrl_amd.batched import BatchedAntsEnv
+    from antsrl_amd.synth import random_actions, synth_init
+    kw = dict(n_rocks=3, deposit_strength=256.0, max_time=7)
+    if _filters()[mode] is not None:
+        kw["filt"] = _filters()[mode]
+    cfg = cm.make_cfg(5, 96, 64, 48, **kw)
+    init = synth_init(cfg, seed=11, wall_density=0.08, n_food_discs=5, food_rmin=2, food_rmax=5)
+    a, b = BatchedAntsEnv(cfg), BatchedAntsEnv(cfg)
+    a.reset(init)
+    b.reset(init)
+    rot, ph = random_actions(cfg, 9, seed=4)
+    rng = np.random.default_rng(3)
+    for t in range(9):
+        for x, y in zip(a.step(rot[t], ph[t]), b.step(rot[t], ph[t])):
+            assert torch.equal(x, y)
+        jit = rng.random((cfg.n_envs, cfg.n_ants)) if inject else None
+        a.update(jit)
+        if t == 3:  # out of order / state changes in the middle of an update are refused; reads are what the phases are FOR
+            with pytest.raises(_lib.AntsrlError, match="phase 0 is next"):
+                b.update_phase(cm.PHASE_ANTS)
+        b.update_phase(cm.PHASE_WALLS, jit)
+        if t == 3:
+            for bad in (lambda: b.step(rot[t], ph[t]), lambda: b.update(None), lambda: b.observe(), lambda: b.update_phase(cm.PHASE_WALLS)):
+                with pytest.raises(_lib.AntsrlError, match="in progress|is next"):
+                    bad()
+            assert int(b.query(cm.Q_TIMESTEP)) == int(a.query(cm.Q_TIMESTEP)) - 1
+            b.read_state(cm.S_PHERO)
+        b.update_phase(cm.PHASE_ROCKS_PHEROMONE)
+        b.update_phase(cm.PHASE_ANTS)
+        b.update_phase(cm.PHASE_ANTHILL)
+        for name in STATE:
+            assert torch.equal(a.read_state(getattr(cm, name)), b.read_state(getattr(cm, name))), "%s after update %d (%s)" % (name, t, mode)
+    assert int(a.query(cm.Q_TIMESTEP)) == int(b.query(cm.Q_TIMESTEP)) == 10
+
+
+@pytest.mark.parametrize("tag", ["scaled", "diffuse"])
+def test_host_objects_between_the_worlds_objects_see_what_the_references_saw(tag):
+    from antsrl_amd.generator import EnvironmentGenerator
+    from antsrl_amd.rl_api import EnvObject, ExplorationReward, Pheromone, RLApi
+    F = dict(np.load(os.path.join(GOLDEN, "contract", "update_phases_ref.npz")))
+    g = lambda k: F["%s_%s" % (tag, k)]  # noqa: E731
+    n, (w, h) = g("init_ants_xyt").shape[0], g("init_walls").shape
+    rocks0 = g("init_rocks")
+
+    class FromFixture(EnvironmentGenerator):  # the reference run's own initial state instead of fresh draws
+        def draw(self):
+            return dict(ants_xyt=g("init_ants_xyt")[None], seed=g("init_seed")[None], walls=g("init_walls").astype(np.uint8)[None],
+                        food=g("init_food").astype(np.float32)[None], anthill_xyr=g("init_anthill_xyr").astype(np.int32)[None], rocks=rocks0[None])
+
+    api = RLApi(ExplorationReward(), 1, 1, 40 / 180 * np.pi, 0.05, 0.5)
+    gen = FromFixture(w, h, n, 2, len(rocks0), None, None, 2000, seed=21)
+    env = gen.generate(api)
+    if tag == "diffuse":  # the reference run patched environment.pheromone.DIFFUSE_FILTER (read at call time, pheromone.py:44):
+        kw, init = api._pending  # the same filter into the batch's configuration
+        api._pending = (dict(kw, filt=g("filter")), init)
+        api._materialize()
+        assert api._backend.cfg.filter_radius == 1
+    api.ants.activate_all_pheromones(np.ones((n, 2)) * 10)
+    ants = api.ants
+    objs = {type(o).__name__: o for o in env.objects}
+    pheros = [o for o in env.objects if isinstance(o, Pheromone)]
+    seen = {int(s): [] for s in F["probe_steps"]}
+
+    class Probe(EnvObject):
+        def __init__(self, environment, step):
+            self.step = step
+            super().__init__(environment)
+
+        def update_step(self):
+            return self.step
+
+        def update(self):
+            seen[self.step].append(dict(ants=ants.ants.copy(), prev=ants.prev_ants.copy(), rocks=np.array(objs["CircleObstacles"].centers),
+                                        phero=np.stack([np.asarray(p.phero) for p in pheros]), food=np.array(objs["Food"].qte),
+                                        anthill_food=float(objs["Anthill"].food), timestep=int(np.asarray(env.timestep).reshape(-1)[0])))
+
+    for s in [int(x) for x in F["probe_steps"]][::-1]:
+        Probe(env, s)
+    rot, ph, jit = g("rot"), g("ph"), g("jitter")
+    for t in range(rot.shape[0]):
+        api.step(rot[t].astype(np.int64), ph[t].astype(np.int64))
+        env.update(wall_jitter=jit[t][None])
+    for s in seen:
+        assert len(seen[s]) == rot.shape[0]
+        for t, rec in enumerate(seen[s]):
+            ctx = "%s: probe at update_step %d, update %d" % (tag, s, t)
+            want = lambda k: g("probe%d_%s" % (s, k))[t]  # noqa: E731
+            assert rec["timestep"] == want("timestep"), ctx
+            assert_xy_close(rec["ants"], want("ants"), 1e-9, ctx)
+            np.testing.assert_array_equal(np.floor(rec["ants"][:, :2]), np.floor(want("ants")[:, :2]), err_msg=ctx + " cells")
+            assert_xy_close(rec["prev"], want("prev"), 1e-9, ctx + " prev")
+            assert_xy_close(rec["rocks"], want("rocks"), 1e-9, ctx + " rocks")
+            np.testing.assert_array_equal(rec["food"], want("food").astype(np.float32), err_msg=ctx + " food")
+            assert rec["anthill_food"] == want("anthill_food"), ctx
+            ok = phero_close(rec["phero"], want("phero"))
+            assert ok.all(), "%s pheromone: %d cells off" % (ctx, (~ok).sum())
+    # the probes between the phases really saw DIFFERENT worlds (else the test pins nothing)
+    d = lambda a, b, k: any((x[k] != y[k]).any() for x, y in zip(seen[a], seen[b]))  # noqa: E731
+    assert d(-2, -1, "ants") and d(-1, 0, "rocks") and d(-1, 0, "phero") and d(500, 999, "phero") and d(500, 999, "prev")
