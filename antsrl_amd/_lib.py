@@ -15,7 +15,8 @@ EXPORTS = ("antsrl_abi_version", "antsrl_cfg_size", "antsrl_last_error", "antsrl
            "antsrl_destroy", "antsrl_reset", "antsrl_generate", "antsrl_step", "antsrl_observe", "antsrl_update", "antsrl_flush",
            "antsrl_step_update", "antsrl_set_timing_events", "antsrl_set_activation", "antsrl_policy_mlp", "antsrl_read_state", "antsrl_state_bytes",
            "antsrl_set_obs_format", "antsrl_query", "antsrl_bench_copy", "antsrl_set_inloop_policy", "antsrl_set_obs_row_stride", "antsrl_mem_alloc", "antsrl_mem_free",
-           "antsrl_mem_trim", "antsrl_mem_stats", "antsrl_update_phase")
+           "antsrl_mem_trim", "antsrl_mem_stats", "antsrl_update_phase",
+           "antsrl_perceptive_field")
 
 _lib = None
 
@@ -52,6 +53,7 @@ def load() -> C.CDLL:
     lib.antsrl_update.argtypes = [vp, vp, vp]
     lib.antsrl_flush.argtypes = [vp, vp]
     lib.antsrl_update_phase.argtypes = [vp, i32, vp, vp]
+    lib.antsrl_perceptive_field.argtypes = [vp, vp, vp]
     lib.antsrl_step_update.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.antsrl_set_timing_events.argtypes = [vp, C.POINTER(vp)]
     lib.antsrl_set_activation.argtypes = [vp, vp, C.c_double, vp]

@@ -521,6 +521,15 @@ class BatchedAntsEnv:
                                                       self._stream()), "set_activation")
         self._loaded = "given an activation matrix"
 
+    def perceptive_field(self) -> torch.Tensor:
+        """RLApi.perceptive_field (RL_api.py:144-153): bool [E, W, H], the cells some ant of the environment perceives
+        (masked cells not counted) — from the positions as they stand: ask right behind step() / observe()."""
+        c = self.cfg
+        out = torch.empty((c.n_envs, c.w, c.h), dtype=torch.uint8, device=self.device)
+        with self._on_device():
+            _lib.check(self.lib.antsrl_perceptive_field(self._h, _ptr(out), self._stream()), "perceptive_field")
+        return out.to(torch.bool)
+
     def read_state(self, which: int) -> torch.Tensor:
         c = self.cfg
         E, N, W, H, Cn, R = c.n_envs, c.n_ants, c.w, c.h, c.n_phero, c.n_rocks

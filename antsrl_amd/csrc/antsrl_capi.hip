@@ -25,6 +25,7 @@ hipError_t antsrl_launch_collect_full(const KP &p, hipStream_t st);
 hipError_t antsrl_launch_reset(const KP &p, const AntsInit *in, hipStream_t st);
 hipError_t antsrl_launch_set_activation(const KP &p, const float *act, hipStream_t st);
 hipError_t antsrl_launch_read_state(const KP &p, int which, int cur, void *dst, hipStream_t st);
+hipError_t antsrl_launch_perceptive_field(const KP &p, uint8_t *dst, hipStream_t st);
 hipError_t antsrl_launch_generate(const KP &p, const AntsGen &g, uint64_t seed, hipStream_t st);
 hipError_t antsrl_launch_phero_wall_clear(const KP &p, hipStream_t st, int buf = 0);
 hipError_t antsrl_launch_phero_renorm(const KP &p, hipStream_t st);
@@ -930,6 +931,17 @@ extern "C" int antsrl_state_bytes(const AntsHandle *h, int which, size_t *bytes)
     if (!h || !bytes) return fail(ANTSRL_E_INVALID, "NULL handle or bytes");
     if (which < 0 || which >= ANTSRL_S_COUNT_) return fail(ANTSRL_E_INVALID, "bad state selector %d", which);
     *bytes = state_bytes(h, which);
+    return ANTSRL_OK;
+}
+
+extern "C" int antsrl_perceptive_field(AntsHandle *h, uint8_t *dst, void *stream)
+{
+    if (!h || !dst) return fail(ANTSRL_E_INVALID, "NULL handle or dst");
+    if (!h->is_reset) return not_reset(h);
+    // (no flush: a DEFERRED update has not touched the positions yet — the field is the last observation's, as in the
+    //  reference, where RLApi.observation computes it; behind an update that has run it is the moved ants')
+    hipError_t e = antsrl_launch_perceptive_field(h->p, dst, (hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail(e, "perceptive_field");
     return ANTSRL_OK;
 }
 

@@ -554,6 +554,43 @@ hipError_t antsrl_launch_set_activation(const KP &p, const float *act, hipStream
     return hipGetLastError();
 }
 
+// RLApi.perceptive_field (RL_api.py:144-153, save_perceptive_field — the viewer's overlay): dst[e][x][y] = 1 where some ant's
+// perception reaches (masked cells not counted), from the ants' positions as they stand — the caller asks right behind the
+// observation.  One thread per (ant, perceived cell); the geometry is k_perceive's (centre shifted by fwd_delta along the
+// heading, offsets rotated by theta + pi / 2, half-to-even rounding, toroidal wrap: RL_api.py:100-119).  Not on the hot path.
+__global__ void __launch_bounds__(256) k_perceptive_field(const KP p, uint8_t *__restrict__ dst)
+{
+    const size_t n = (size_t)p.E * p.N * p.PP;
+    const size_t G = (size_t)p.W * p.H;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t a = i / p.PP;
+        const int q = (int)(i - a * p.PP);
+        if (p.has_mask && !p.mask[q]) continue;
+        const size_t e = a / p.N;
+        const double th = p.s.theta[a];
+        double sn, cs, sn2, cs2;
+        sincos(th + PI_D * 0.5, &sn2, &cs2);
+        double cx = p.s.x[a], cy = p.s.y[a];
+        if (p.fwd_delta != 0.0) {
+            sincos(th, &sn, &cs);
+            cx += cs * p.fwd_delta;
+            cy += sn * p.fwd_delta;
+        }
+        const double ox = (double)(q % p.P - p.r) * p.delta, oy = (double)(q / p.P - p.r) * p.delta;
+        const int ix = wrap_index((int)rint((cs2 * ox - sn2 * oy) + cx), p.W);
+        const int iy = wrap_index((int)rint((sn2 * ox + cs2 * oy) + cy), p.H);
+        dst[e * G + (size_t)ix * p.H + iy] = 1;
+    }
+}
+
+hipError_t antsrl_launch_perceptive_field(const KP &p, uint8_t *dst, hipStream_t st)
+{
+    hipError_t e = hipMemsetAsync(dst, 0, (size_t)p.E * p.W * p.H, st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_perceptive_field, dim3(grid_for((size_t)p.E * p.N * p.PP)), dim3(256), 0, st, p, dst);
+    return hipGetLastError();
+}
+
 hipError_t antsrl_launch_read_state(const KP &p, int which, int cur, void *dst, hipStream_t st)
 {
     hipLaunchKernelGGL(k_read_state, dim3(grid_for((size_t)p.E * p.W * p.H)), dim3(256), 0, st, p, which, cur, dst);

@@ -407,8 +407,8 @@ class RLApi(EnvObject):  # environment/RL_api.py:22-204
         self.max_speed, self.max_rot_speed = max_speed, max_rot_speed
         self.carry_speed_reduction = carry_speed_reduction
         self.backward_speed_reduction = backward_speed_reduction
-        self.save_perceptive_field = False  # GUI only (RL_api.py:49,144-153): accepted, not produced
-        self.perceptive_field = None
+        self.save_perceptive_field = False  # (RL_api.py:49; main.py:51 sets it for the viewer) -> `perceptive_field` after
+        self.perceptive_field = None        # every observation: bool [w, h] ([E, w, h] for a batch), RL_api.py:144-153
         self.as_numpy = as_numpy
         self._pending = None  # (base cfg kwargs, init arrays) from the generator
         self._backend = None
@@ -480,9 +480,16 @@ class RLApi(EnvObject):  # environment/RL_api.py:22-204
         """RL_api.py:96-165 -> (perception [n,P,P,K], agent_state [n,2], state [n,2+C])."""
         b = self._backend
         obs, ast, rew = b.observe()
+        self._field()
         self.reward.rewards = self._out(rew)
         state = self._state()
         return self._out(obs), self._out(ast), state
+
+    def _field(self):  # RL_api.py:144-153
+        if self.save_perceptive_field:
+            f = self._backend.perceptive_field()
+            f = f.cpu().numpy() if self.as_numpy else f
+            self.perceptive_field = f[0] if self._backend.cfg.n_envs == 1 else f
 
     def _state(self):  # RL_api.py:155-158
         import torch
@@ -496,6 +503,7 @@ class RLApi(EnvObject):  # environment/RL_api.py:22-204
         """RL_api.py:168-204 -> (perception, agent_state, reward, done)."""
         b = self._backend
         obs, ast, rew, done = b.step(self._acts(rotation), self._acts(on_off_pheromones))
+        self._field()
         if self.as_numpy:  # the four outputs in one device-to-host copy
             obs, ast, rew, done = b.outputs_to_host()
             fold = lambda t: t.reshape((t.shape[0] * t.shape[1],) + t.shape[2:])

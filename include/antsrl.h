@@ -460,6 +460,13 @@ int antsrl_set_inloop_policy(AntsHandle *h, int32_t n_features, const float *w1,
  * api.ants.ants, pheromone.phero, food.qte, anthill.food. */
 int antsrl_read_state(AntsHandle *h, int which, void *dst, void *stream);
 
+/* RLApi.perceptive_field (environment/RL_api.py:144-153; main.py:51 sets save_perceptive_field for the viewer): dst
+ * uint8 [E][W][H] = 1 where the perception of some ant of the environment reaches — masked cells not counted — computed from
+ * the ants' positions as they stand: call it right behind antsrl_step / antsrl_observe (the reference computes it inside
+ * RLApi.observation).  A deferred update (antsrl_update with the library's jitter) has not moved anything yet and is NOT
+ * flushed by this call. */
+int antsrl_perceptive_field(AntsHandle *h, uint8_t *dst, void *stream);
+
 /* Size in bytes of what antsrl_read_state(which) writes. */
 int antsrl_state_bytes(const AntsHandle *h, int which, size_t *bytes);
 

@@ -11,7 +11,7 @@ CircleObstacles, Pheromone, RLApi), after Ants (999), after Anthill (1000).  The
 circle obstacles, float activation, 32 ants, and runs 10 x (api.step, env.update) with the shipped centre-only filter
 ("scaled") and with a 3 x 3 diffusion filter ("diffuse"); every probe records, at its own update(), what the world looks
 like at that moment: ants (x, y, theta), previous positions, rock centres, both pheromone grids, food, anthill.food,
-env.timestep.  Same import shims as make_golden.py; only inputs and recorded outputs are stored."""
+env.timestep.  Also recorded: RLApi.perceptive_field after every step (save_perceptive_field, main.py:51; RL_api.py:144-153).  Same import shims as make_golden.py; only inputs and recorded outputs are stored."""
 import os
 import random
 import sys
@@ -85,9 +85,12 @@ def run(tag, filt, seed=21, w=64, h=64, n_ants=32, n_rocks=3, steps=10):
         rot = rng.integers(-1, 2, (steps, n_ants))
         ph = rng.integers(0, 3, (steps, n_ants))
         jit = np.zeros((steps, n_ants))
+        fields = []
+        api.save_perceptive_field = True  # main.py:51: RLApi.observation then leaves the cells the ants perceive (RL_api.py:144-153)
         real_random = np.random.random
         for t in range(steps):
             api.step(rot[t], ph[t])
+            fields.append(api.perceptive_field.copy())
             draws = []
 
             def recording(n=None):
@@ -102,6 +105,7 @@ def run(tag, filt, seed=21, w=64, h=64, n_ants=32, n_rocks=3, steps=10):
             d = np.concatenate(draws) if draws else np.zeros(0)
             jit[t, :len(d)] = d
         rec["%s_rot" % tag], rec["%s_ph" % tag], rec["%s_jitter" % tag] = rot.astype(np.int8), ph.astype(np.int8), jit
+        rec["%s_perceptive_field" % tag] = np.packbits(np.stack(fields), axis=-1)  # [steps, w, h / 8]
         for s in PROBE_STEPS:
             for k in ("ants", "prev", "rocks", "phero", "food"):
                 rec["%s_probe%d_%s" % (tag, s, k)] = np.stack([x[k] for x in seen[s]])

@@ -8,7 +8,7 @@ missing" #2).
     rocks, library and injected jitter; out-of-order calls and state changes in the middle of an update are refused;
   * tests/golden/contract/update_phases_ref.npz (tests/golden/make_phase_golden.py: the reference itself with six recording
     probes at update_step -2, -1, 0, 500, 999, 1000): the shim's host objects see, at their own update(), what the
-    reference's saw."""
+    reference's saw; RLApi.perceptive_field (save_perceptive_field, main.py:51) equals the reference's after every step."""
 import os
 
 import numpy as np
@@ -114,8 +114,13 @@ def test_host_objects_between_the_worlds_objects_see_what_the_references_saw(tag
     for s in [int(x) for x in F["probe_steps"]][::-1]:
         Probe(env, s)
     rot, ph, jit = g("rot"), g("ph"), g("jitter")
+    api.save_perceptive_field = True   # main.py:51
+    want_field = np.unpackbits(g("perceptive_field"), axis=-1).astype(bool)
     for t in range(rot.shape[0]):
         api.step(rot[t].astype(np.int64), ph[t].astype(np.int64))
+        # RLApi.perceptive_field (RL_api.py:144-153): the cells the ants' (unmasked) perception reaches, cell for cell
+        assert api.perceptive_field.dtype == bool and api.perceptive_field.shape == (w, h)
+        np.testing.assert_array_equal(api.perceptive_field, want_field[t], err_msg="%s: perceptive_field after step %d" % (tag, t))
         env.update(wall_jitter=jit[t][None])
     for s in seen:
         assert len(seen[s]) == rot.shape[0]
