@@ -8,8 +8,12 @@ done[E_local] (u8) each step, so that every rank / the host sees the full batch.
 
 Backend "nccl" is RCCL on ROCm (over xGMI inside a node); "gloo" is used by the CPU tests and by the one-GPU rehearsal of
 world > 1 (tests/test_a_gpu_dist.py).  Set TORCH_NCCL_HIGH_PRIORITY=1 before init_process_group (bench.py does): on RCCL's
-default-priority stream the per-step gather shares a hardware queue with the step's kernels and costs +41 us per 0.24 ms step
-(one rank, measured: profiles/r04/dist_overhead_ab.txt); on a high-priority stream +4 us.
+default-priority stream the per-step gather shares a hardware queue with the step's kernels.  What one collective per step
+costs a rank, measured with ONE RCCL rank at c3 (0.198 ms/step without it; profiles/r05/dist_overhead_ab.txt): +24 us on the
+high-priority stream, +36-50 us on the default one — not host time (67 us of enqueue per step, dist_host_time.txt), not the
+SDMA engine, not k_perceive's occupancy (…_sdma_ab.txt, …_occupancy_ab.txt): the cross-stream event hand-overs around the
+collective (an event record between two kernels costs the stream ~15 us of idle time on this runtime).  (Round 4 read +4 us
+off a 0.240 ms step.)
 
 The gather is ONE collective per step: reward and done travel in a single fused fp32 buffer
 [E_local, N+1] (done in the last column — xGMI all-gathers of this size are latency-bound, so one
@@ -54,8 +58,15 @@ class RewardGather:
         self.max_local = max(hi - lo for lo, hi in self.ranges)
         self.equal = all(hi - lo == self.max_local for lo, hi in self.ranges)
         # fused payload: [max_local, N+1] per rank, column N carries `done`
-        self._send = torch.zeros((self.max_local, n_ants + 1), dtype=torch.float32, device=device)
-        self._recv = torch.empty((self.world * self.max_local, n_ants + 1), dtype=torch.float32, device=device)
+        # TWO staging slots used alternately (round 5): the gather of step t reads slot t % 2 while step t + 1 fills the other,
+        # so the step's stream never waits for the collective it has just launched — only for the one before it, which has
+        # had a whole step to finish.  (With one slot every step paid the collective's full latency: +31 us per 0.198 ms
+        # step with one RCCL rank, profiles/r05/dist_overhead_ab.txt.)
+        self._sends = [torch.zeros((self.max_local, n_ants + 1), dtype=torch.float32, device=device) for _ in range(2)]
+        self._recvs = [torch.empty((self.world * self.max_local, n_ants + 1), dtype=torch.float32, device=device) for _ in range(2)]
+        self._works = [None, None]
+        self._slot = 0          # the slot of the most recent start()
+        self._send, self._recv = self._sends[0], self._recvs[0]
         self._work: Optional[dist.Work] = None
         if not self.equal:
             self._keep = torch.cat([torch.arange(r * self.max_local, r * self.max_local + (h - l))
@@ -66,17 +77,25 @@ class RewardGather:
         current stream; the caller may enqueue the next step right away."""
         lo, hi = self.ranges[self.rank]
         assert reward_local.shape == (hi - lo, self.N) and done_local.shape == (hi - lo,)
-        self.finish()  # the send buffer is reused: the previous gather must have consumed it
+        k = self._slot ^ 1
+        if self._works[k] is not None:  # the slot is reused: the gather that last read it (two steps ago) must have consumed it
+            self._works[k].wait()
+            self._works[k] = None
+        self._slot = k
+        self._send, self._recv = self._sends[k], self._recvs[k]
         self._send[: hi - lo, : self.N].copy_(reward_local)
         self._send[: hi - lo, self.N].copy_(done_local)
-        self._work = dist.all_gather_into_tensor(self._recv, self._send, group=self.group, async_op=True)
+        self._work = self._works[k] = dist.all_gather_into_tensor(self._recv, self._send, group=self.group, async_op=True)
 
     def finish(self):
         """Wait for the gather launched by start(); -> (reward [E_total, N], done [E_total] uint8) on
         every rank, or None if nothing is pending."""
         if self._work is None:
             return None
-        self._work.wait()
+        for k in (self._slot ^ 1, self._slot):  # (the older gather first: both are done when this returns)
+            if self._works[k] is not None:
+                self._works[k].wait()
+                self._works[k] = None
         self._work = None
         return self.result()
 

@@ -232,6 +232,12 @@ def main():
     import numpy as np
     import torch
 
+    # ONE JSON line on stdout, whatever the libraries underneath print there (RCCL writes its version banner — five lines — to
+    # STDOUT when the process group comes up): file descriptor 1 goes to stderr for the run, the line to the real stdout.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -605,8 +611,9 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    sys.stdout.flush()
     if rank == 0:
-        print(json.dumps(out))
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
 
 
 if __name__ == "__main__":
