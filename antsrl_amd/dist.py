@@ -12,8 +12,9 @@ default-priority stream the per-step gather shares a hardware queue with the ste
 costs a rank, measured with ONE RCCL rank at c3 (0.198 ms/step without it; profiles/r05/dist_overhead_ab.txt): +24 us on the
 high-priority stream, +36-50 us on the default one — not host time (67 us of enqueue per step, dist_host_time.txt), not the
 SDMA engine, not k_perceive's occupancy (…_sdma_ab.txt, …_occupancy_ab.txt): the cross-stream event hand-overs around the
-collective (an event record between two kernels costs the stream ~15 us of idle time on this runtime).  (Round 4 read +4 us
-off a 0.240 ms step.)
+collective (an event record between two kernels costs the stream ~15 us of idle time on this runtime): a blocking
+collective on the step's own stream (mode "inline" below) costs +8…+12 us with one rank, but puts the collective's latency
+inside the step (dist_overhead_ab_inline.txt).  (Round 4 read +4 us off a 0.240 ms step.)
 
 The gather is ONE collective per step: reward and done travel in a single fused fp32 buffer
 [E_local, N+1] (done in the last column — xGMI all-gathers of this size are latency-bound, so one
@@ -148,13 +149,22 @@ class RewardGather:
                                "and the gather would not be ordered" % slot)
         z["work"][slot] = dist.all_gather_into_tensor(z["recv"][slot], z["send"][slot], group=self.group, async_op=True)
 
+    def gather_slot_inline(self, slot: int) -> None:
+        """All-gather send slot `slot` as a BLOCKING collective (async_op=False): ProcessGroupNCCL then enqueues it on the
+        current stream, behind the step's kernels and ahead of the next step's — no side stream, no event hand-over, and the
+        collective's whole latency inside the step.  finish_slot(slot) reads the result."""
+        z = self._zc
+        dist.all_gather_into_tensor(z["recv"][slot], z["send"][slot], group=self.group, async_op=False)
+        z["inline"] = True
+
     def finish_slot(self, slot: int):
         """-> (reward [E_total, N], done [E_total] uint8) of the gather started on `slot`, or None."""
         z = getattr(self, "_zc", None)
-        if z is None or z["work"][slot] is None:
+        if z is None or (z["work"][slot] is None and not z.get("inline")):
             return None
-        z["work"][slot].wait()
-        z["work"][slot] = None
+        if z["work"][slot] is not None:
+            z["work"][slot].wait()
+            z["work"][slot] = None
         rb = z["recv"][slot].view(self.world, z["nb"])
         rew = rb[:, : self.max_local * self.N * 4].view(torch.float32).view(self.world, self.max_local, self.N)  # (a view: rows are 16-byte aligned)
         done = rb[:, self.max_local * self.N * 4: self.max_local * self.N * 4 + self.max_local]
@@ -180,11 +190,13 @@ class ShardedStepper:
     mode "staged" (default): the step writes the env's own reward / done tensors, start() snapshots them into the
     send buffer (two small device copies) and launches the all-gather asynchronously under the next step.
     mode "zero_copy": the env's reward / done are re-pointed at the gather's alternating send slots, so the kernels
-    write the collective's payload in place (experimental, see RewardGather.outputs)."""
+    write the collective's payload in place (experimental, see RewardGather.outputs).
+    mode "inline": zero_copy's in-place payload on ONE slot, gathered by a blocking collective on the step's own stream
+    (RewardGather.gather_slot_inline): nothing overlaps, nothing is handed between streams."""
 
     def __init__(self, env, gather: Optional[RewardGather], mode: str = "staged"):
-        if mode not in ("staged", "zero_copy"):
-            raise ValueError("mode must be 'staged' or 'zero_copy'")
+        if mode not in ("staged", "zero_copy", "inline"):
+            raise ValueError("mode must be 'staged', 'zero_copy' or 'inline'")
         self.env, self.gather, self.mode = env, gather, mode
         self._last_slot = None
 
@@ -192,8 +204,14 @@ class ShardedStepper:
         g = self.gather
         if g is not None and self.mode == "zero_copy":
             self.env.reward, self.env.done = g.outputs(t % 2)
+        elif g is not None and self.mode == "inline" and self._last_slot is None:
+            self.env.reward, self.env.done = g.outputs(0)
         do_step()
         if g is None:
+            return
+        if self.mode == "inline":
+            g.gather_slot_inline(0)
+            self._last_slot = 0
             return
         # the path's only exchange: the reward / done all-gather, one fused collective per
         # step, left running under the next step's kernels
@@ -208,6 +226,8 @@ class ShardedStepper:
         g = self.gather
         if g is None:
             return None
+        if self.mode == "inline":
+            return g.finish_slot(0) if self._last_slot is not None else None
         if self.mode == "zero_copy":
             last = self._last_slot
             out = None

@@ -203,7 +203,7 @@ def main():
     ap.add_argument("--act-path", default="auto", choices=["auto", "meta", "kact"],
                     help="AntsCfg.act_path: auto (the library's measured choice), meta (k_move + k_perceive), kact (round 1's "
                          "single kernel) — for A/B runs on one box")
-    ap.add_argument("--gather", default="staged", choices=["staged", "zero_copy"],
+    ap.add_argument("--gather", default="staged", choices=["staged", "zero_copy", "inline"],
                     help="N > 1: how reward/done reach the all-gather (zero_copy: the kernels write the send slots in place; "
                          "experimental until it has run on RCCL with more than one rank)")
     ap.add_argument("--no-explicit-sweep", action="store_true",
@@ -442,7 +442,7 @@ def main():
         with_g = min(local_region(stepper) for _ in range(2))
         without_g = min(local_region(plain) for _ in range(2))
         gather_overhead_us = round((with_g - without_g) * 1e6, 2)
-        if args.gather == "zero_copy":  # (the plain stepper left reward / done on a send slot: harmless, the run is over)
+        if args.gather in ("zero_copy", "inline"):  # (the plain stepper left reward / done on a send slot: harmless, the run is over)
             pass
     pt = getattr(env, "placement_trials", None) if placement else None
     mine = dict(rank=rank, env_id_base=env_id_base, ms_per_step=float(np.median(region_local_s)) / K * 1e3,

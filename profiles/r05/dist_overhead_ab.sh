@@ -10,4 +10,5 @@ for i in 1 2; do
   run staged_hp ANTSRL_BENCH_FORCE_DIST=1
   run staged_lowprio ANTSRL_BENCH_FORCE_DIST=1 TORCH_NCCL_HIGH_PRIORITY=0
   GATHER=zero_copy run zc_hp ANTSRL_BENCH_FORCE_DIST=1
+  GATHER=inline run inline ANTSRL_BENCH_FORCE_DIST=1
 done

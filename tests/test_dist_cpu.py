@@ -122,7 +122,7 @@ def _stepper_worker(rank, world, port, E, N, mode, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["staged", "zero_copy"])
+@pytest.mark.parametrize("mode", ["staged", "zero_copy", "inline"])
 def test_bench_step_loop_two_ranks(mode):
     """bench.py's N > 1 sequence (antsrl_amd.dist.ShardedStepper: env.reward / env.done re-pointed at the gather's
     slots or snapshotted, one async all-gather per step, drain at the region's end) with two gloo ranks and a
@@ -185,7 +185,7 @@ def _identity_worker(rank, world, port, E, N, mode, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,E,mode", [(2, 5, "staged"), (3, 7, "zero_copy")])
+@pytest.mark.parametrize("world,E,mode", [(2, 5, "staged"), (3, 7, "zero_copy"), (2, 6, "inline")])
 def test_sharded_run_equals_the_single_process_batch(world, E, mode):
     """world gloo ranks step their blocks of one batch (shard_cfg: env_id_base = the block's first global id) with the
     library's OWN wall jitter and all-gather reward / done every step: every rank sees exactly what one process stepping
