@@ -47,10 +47,36 @@ def shard_cfg(n_envs_total: int, rank: int, world: int, n_ants: int, w: int, h: 
     return make_cfg(hi - lo, n_ants, w, h, env_id_base=lo, n_envs_total=n_envs_total, **make_cfg_kwargs), lo, hi
 
 
-class RewardGather:
-    """Pre-allocated all-gather of (reward, done) across the ranks that share an env batch."""
+class _Works:
+    """The works of one grouped exchange behind the one-collective interface (wait())."""
 
-    def __init__(self, n_envs_total: int, n_ants: int, device, group=None):
+    def __init__(self, works):
+        self.works = list(works)
+
+    def wait(self):
+        while self.works:  # (once each: a second wait() on a gloo send / receive blocks for ever)
+            self.works.pop(0).wait()
+
+
+class RewardGather:
+    """Pre-allocated all-gather of (reward, done) across the ranks that share an env batch.
+
+    algo "collective" (default): ONE `all_gather_into_tensor`; RCCL chooses the algorithm (its rings / trees over the links it
+    found: `NCCL_ALGO`, `NCCL_PROTO` are the knobs).
+    algo "direct": SURVEY.md §8(e)'s one-hop form, spelled out: every rank sends its block to each of the other world - 1 ranks
+    and receives theirs, as ONE grouped batch of point-to-point operations (`batch_isend_irecv`: on RCCL a single
+    ncclGroupStart / End launch), so that on a fully connected xGMI node every block rides the link between its two ranks and
+    nothing is forwarded; the rank's own block is a device copy.  Same result, same buffers, same start / finish; opt-in
+    (`bench.py --gather-algo direct`) until both have been timed on a node with more than one GPU — the gloo tests run it with
+    two and three ranks."""
+
+    def __init__(self, n_envs_total: int, n_ants: int, device, group=None, algo: str = "collective"):
+        if algo not in ("collective", "direct"):
+            raise ValueError("algo must be 'collective' or 'direct'")
+        if algo == "direct" and torch.device(device).type == "cuda" and dist.get_backend(group) == "gloo":
+            raise ValueError("RewardGather(algo='direct') on device tensors needs the RCCL ('nccl') backend: gloo's send / "
+                             "receive take host memory")
+        self.algo = algo
         self.group = group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
@@ -68,10 +94,26 @@ class RewardGather:
         self._works = [None, None]
         self._slot = 0          # the slot of the most recent start()
         self._send, self._recv = self._sends[0], self._recvs[0]
-        self._work: Optional[dist.Work] = None
+        self._work = None
         if not self.equal:
             self._keep = torch.cat([torch.arange(r * self.max_local, r * self.max_local + (h - l))
                                     for r, (l, h) in enumerate(self.ranges)]).to(device)
+
+    def _exchange(self, recv: torch.Tensor, send: torch.Tensor):
+        """Launches the exchange of one slot (recv = world equal blocks along dim 0, block r from rank r) without blocking the
+        current stream; -> something with wait()."""
+        if self.algo == "collective" or self.world == 1:
+            return dist.all_gather_into_tensor(recv, send, group=self.group, async_op=True)
+        n = recv.shape[0] // self.world
+        peer = (lambda r: r) if self.group is None else (lambda r: dist.get_global_rank(self.group, r))
+        ops = []
+        for d in range(1, self.world):  # rank + d and rank - d: at every distance the whole node forms disjoint pairs of links
+            to, frm = (self.rank + d) % self.world, (self.rank - d) % self.world
+            ops.append(dist.P2POp(dist.isend, send, peer(to), self.group))
+            ops.append(dist.P2POp(dist.irecv, recv[frm * n:(frm + 1) * n], peer(frm), self.group))
+        works = dist.batch_isend_irecv(ops)
+        recv[self.rank * n:(self.rank + 1) * n].copy_(send)  # (the rank's own block: on the caller's stream, like its readers)
+        return _Works(works)
 
     def start(self, reward_local: torch.Tensor, done_local: torch.Tensor) -> None:
         """Snapshot this rank's (reward, done) and launch the all-gather without blocking the
@@ -86,7 +128,7 @@ class RewardGather:
         self._send, self._recv = self._sends[k], self._recvs[k]
         self._send[: hi - lo, : self.N].copy_(reward_local)
         self._send[: hi - lo, self.N].copy_(done_local)
-        self._work = self._works[k] = dist.all_gather_into_tensor(self._recv, self._send, group=self.group, async_op=True)
+        self._work = self._works[k] = self._exchange(self._recv, self._send)
 
     def finish(self):
         """Wait for the gather launched by start(); -> (reward [E_total, N], done [E_total] uint8) on
@@ -147,7 +189,7 @@ class RewardGather:
         if z.get("stream") and z["stream"][slot] != self._current_stream(self._send.device):
             raise RuntimeError("RewardGather.start_slot: the current stream changed since outputs(%d): the step kernels "
                                "and the gather would not be ordered" % slot)
-        z["work"][slot] = dist.all_gather_into_tensor(z["recv"][slot], z["send"][slot], group=self.group, async_op=True)
+        z["work"][slot] = self._exchange(z["recv"][slot], z["send"][slot])
 
     def gather_slot_inline(self, slot: int) -> None:
         """All-gather send slot `slot` as a BLOCKING collective (async_op=False): ProcessGroupNCCL then enqueues it on the

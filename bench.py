@@ -206,6 +206,9 @@ def main():
     ap.add_argument("--gather", default="staged", choices=["staged", "zero_copy", "inline"],
                     help="N > 1: how reward/done reach the all-gather (zero_copy: the kernels write the send slots in place; "
                          "experimental until it has run on RCCL with more than one rank)")
+    ap.add_argument("--gather-algo", default="collective", choices=["collective", "direct"],
+                    help="N > 1: one all_gather_into_tensor (RCCL picks the algorithm) or SURVEY 8(e)'s one-hop form as a grouped "
+                         "batch of sends / receives, every block on the link between its two ranks (RCCL only)")
     ap.add_argument("--no-explicit-sweep", action="store_true",
                     help="skip the short extra run with the per-step sweep kernel forced (explicit_sweep record)")
     ap.add_argument("--policy", default=None, choices=["random", "mlp"],
@@ -320,7 +323,7 @@ def main():
     gather = None
     if dist is not None:
         from antsrl_amd.dist import RewardGather
-        gather = RewardGather(world * E, cfg.n_ants, dev)
+        gather = RewardGather(world * E, cfg.n_ants, dev, algo=args.gather_algo)
 
     policy, inloop, want_obs = None, False, True
     if policy_kind == "mlp":
@@ -536,6 +539,7 @@ def main():
             "ms_per_step_spread": round((max(region_s) - min(region_s)) / K * 1e3, 5),
             "rccl_ranks": (dist.get_world_size() if dist is not None else 1),  # ranks of the process group (one per GPU)
             "collective_backend": (backend if dist is not None else None),   # "nccl" = RCCL; "gloo" = the one-GPU rehearsal
+            "gather": ({"mode": args.gather, "algo": args.gather_algo} if dist is not None else None),
             "env_id_base_per_rank": bases, "n_envs_total": world * E,
             # per-rank figures, rank order: each rank's OWN median region (before the MAX over ranks), its device, what its
             # placement tuner chose (and the default pair's time beside it: the untuned figure), what the gather costs it

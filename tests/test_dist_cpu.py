@@ -108,7 +108,8 @@ def _stepper_worker(rank, world, port, E, N, mode, q):
         from antsrl_amd.dist import ShardedStepper
         lo, hi = shard_range(E, rank, world)
         env = _FakeEnv(lo, hi, N)
-        st = ShardedStepper(env, RewardGather(E, N, "cpu"), mode)
+        mode, _, algo = mode.partition("/")
+        st = ShardedStepper(env, RewardGather(E, N, "cpu", algo=algo or "collective"), mode)
         seen = []
         for t in range(5):  # bench.py's loop: step, gather left in flight under the next step
             st.step(t, lambda: env.step_update(t))
@@ -122,7 +123,7 @@ def _stepper_worker(rank, world, port, E, N, mode, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["staged", "zero_copy", "inline"])
+@pytest.mark.parametrize("mode", ["staged", "zero_copy", "inline", "staged/direct", "zero_copy/direct"])
 def test_bench_step_loop_two_ranks(mode):
     """bench.py's N > 1 sequence (antsrl_amd.dist.ShardedStepper: env.reward / env.done re-pointed at the gather's
     slots or snapshotted, one async all-gather per step, drain at the region's end) with two gloo ranks and a
@@ -174,7 +175,8 @@ def _identity_worker(rank, world, port, E, N, mode, q):
         init = synth_init(cfg, seed=50, env_offset=lo, wall_density=0.2, n_food_discs=3, food_rmin=2, food_rmax=4)
         rot, ph = random_actions(make_cfg(E, N, 32, 32), 6, seed=2)  # the whole batch's actions, sliced per rank
         env = _OracleEnv(cfg, init)
-        st = ShardedStepper(env, RewardGather(E, N, "cpu"), mode)
+        mode, _, algo = mode.partition("/")
+        st = ShardedStepper(env, RewardGather(E, N, "cpu", algo=algo or "collective"), mode)
         seen = []
         for t in range(6):
             st.step(t, lambda: env.step_update(rot[t][lo:hi], ph[t][lo:hi]))
@@ -185,7 +187,7 @@ def _identity_worker(rank, world, port, E, N, mode, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,E,mode", [(2, 5, "staged"), (3, 7, "zero_copy"), (2, 6, "inline")])
+@pytest.mark.parametrize("world,E,mode", [(2, 5, "staged"), (3, 7, "zero_copy"), (2, 6, "inline"), (3, 7, "staged/direct")])
 def test_sharded_run_equals_the_single_process_batch(world, E, mode):
     """world gloo ranks step their blocks of one batch (shard_cfg: env_id_base = the block's first global id) with the
     library's OWN wall jitter and all-gather reward / done every step: every rank sees exactly what one process stepping
